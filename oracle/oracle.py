@@ -1,0 +1,135 @@
+"""ctypes front-end of oracle/libdoppel_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The product package
+(doppel-speller_amd) never does: it fails loudly when its HIP library is missing.
+
+Each wrapper names the reference function it restates; `typing` is 'numba' (the specification) or 'numpy' (what the
+golden vectors were captured with) -- see the header of doppel_oracle.c.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdoppel_oracle.so")
+_TYPING = {"numba": 0, "numpy": 1}
+FEATURES_COUNT = 66
+WORDS = 15
+_lib = None
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (idempotent)."""
+    source = os.path.join(_HERE, "doppel_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(source):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libdoppel_oracle.so"])
+    return _LIB_PATH
+
+
+def _ptr(array, ctype):
+    return array.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        handle = ctypes.CDLL(_LIB_PATH)
+        handle.ds_oracle_num_threads.restype = ctypes.c_int
+        handle.ds_oracle_fast_arg_top_k.restype = ctypes.c_int64
+        handle.ds_oracle_jaccard_topk.restype = ctypes.c_int64
+        handle.ds_oracle_levenshtein_ratio.restype = ctypes.c_uint8
+        handle.ds_oracle_feature_cells.restype = ctypes.c_int64
+        _lib = handle
+    return _lib
+
+
+def num_threads():
+    return int(lib().ds_oracle_num_threads())
+
+
+def fast_jaccard(max_intersection_possible, columns, rowptr, truth_idx, idf32, sums32):
+    """match_maker.py:16-50 -> float64[N]."""
+    n = sums32.shape[0]
+    columns = np.ascontiguousarray(columns, dtype=np.int32)
+    scores = np.empty(n, dtype=np.float32)
+    out = np.empty(n, dtype=np.float64)
+    lib().ds_oracle_fast_jaccard(
+        ctypes.c_int64(n), ctypes.c_double(float(max_intersection_possible)), _ptr(columns, ctypes.c_int32),
+        ctypes.c_int64(columns.shape[0]), _ptr(rowptr, ctypes.c_int64), _ptr(truth_idx, ctypes.c_int32),
+        _ptr(idf32, ctypes.c_float), _ptr(sums32, ctypes.c_float), _ptr(scores, ctypes.c_float),
+        _ptr(out, ctypes.c_double))
+    return out
+
+
+def fast_arg_top_k(array, k, typing="numba"):
+    """match_maker.py:53-71 -> int64[<=k] row indexes, descending index order."""
+    array = np.ascontiguousarray(array, dtype=np.float64)
+    out = np.empty(k, dtype=np.int64)
+    found = lib().ds_oracle_fast_arg_top_k(_ptr(array, ctypes.c_double), ctypes.c_int64(array.shape[0]),
+                                           ctypes.c_int32(k), ctypes.c_int32(_TYPING[typing]),
+                                           _ptr(out, ctypes.c_int64))
+    return out[:found]
+
+
+def jaccard_topk(rowptr, truth_idx, idf32, sums32, q_rowptr, q_cols, q_maxint, k, typing="numba"):
+    """match_maker.py:192-203 batched -> int32[Q, k] truth row indexes (descending row index per query)."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    truth_idx = np.ascontiguousarray(truth_idx, dtype=np.int32)
+    idf32 = np.ascontiguousarray(idf32, dtype=np.float32)
+    sums32 = np.ascontiguousarray(sums32, dtype=np.float32)
+    q_rowptr = np.ascontiguousarray(q_rowptr, dtype=np.int64)
+    q_cols = np.ascontiguousarray(q_cols, dtype=np.int32)
+    q_maxint = np.ascontiguousarray(q_maxint, dtype=np.float64)
+    n_queries = q_rowptr.shape[0] - 1
+    out = np.empty((n_queries, k), dtype=np.int32)
+    status = lib().ds_oracle_jaccard_topk(
+        _ptr(rowptr, ctypes.c_int64), _ptr(truth_idx, ctypes.c_int32), _ptr(idf32, ctypes.c_float),
+        _ptr(sums32, ctypes.c_float), ctypes.c_int64(sums32.shape[0]), _ptr(q_rowptr, ctypes.c_int64),
+        _ptr(q_cols, ctypes.c_int32), _ptr(q_maxint, ctypes.c_double), ctypes.c_int64(n_queries), ctypes.c_int32(k),
+        ctypes.c_int32(_TYPING[typing]), _ptr(out, ctypes.c_int32))
+    if status != 0:
+        raise Exception("top_matches.shape[0] != self.top_n")  # match_maker.py:188-189
+    return out
+
+
+def levenshtein_ratio(a, b, typing="numba"):
+    """feature_engineering.py:25-63 on two uint8 code arrays."""
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    return int(lib().ds_oracle_levenshtein_ratio(_ptr(a, ctypes.c_uint8), ctypes.c_int32(a.shape[0]),
+                                                 _ptr(b, ctypes.c_uint8), ctypes.c_int32(b.shape[0]),
+                                                 ctypes.c_int32(_TYPING[typing])))
+
+
+def construct_features(title_len, truth_len, title_enc, truth_enc, counts, space_code, n_truth, typing="numba"):
+    """feature_engineering.py:75-169 -> float32[n, 66]."""
+    title_len = np.ascontiguousarray(title_len, dtype=np.uint8)
+    truth_len = np.ascontiguousarray(truth_len, dtype=np.uint8)
+    title_enc = np.ascontiguousarray(title_enc, dtype=np.uint8)
+    truth_enc = np.ascontiguousarray(truth_enc, dtype=np.uint8)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    n = title_len.shape[0]
+    assert title_enc.shape == truth_enc.shape and title_enc.shape[0] == n and counts.shape == (n, WORDS)
+    out = np.empty((n, FEATURES_COUNT), dtype=np.float32)
+    lib().ds_oracle_construct_features(
+        _ptr(title_len, ctypes.c_uint8), _ptr(truth_len, ctypes.c_uint8), _ptr(title_enc, ctypes.c_uint8),
+        _ptr(truth_enc, ctypes.c_uint8), _ptr(counts, ctypes.c_uint32), ctypes.c_uint8(int(space_code)),
+        ctypes.c_uint32(int(n_truth)), ctypes.c_int64(n), ctypes.c_int64(title_enc.shape[1]),
+        ctypes.c_int32(_TYPING[typing]), _ptr(out, ctypes.c_float))
+    return out
+
+
+def feature_cells(title_len, truth_len, title_enc, truth_enc, space_code):
+    """DP cells visited per pair (SURVEY.md section 8d work formula)."""
+    title_enc = np.ascontiguousarray(title_enc, dtype=np.uint8)
+    truth_enc = np.ascontiguousarray(truth_enc, dtype=np.uint8)
+    out = np.empty(title_enc.shape[0], dtype=np.int64)
+    for i in range(title_enc.shape[0]):
+        out[i] = lib().ds_oracle_feature_cells(
+            ctypes.c_uint8(int(title_len[i])), ctypes.c_uint8(int(truth_len[i])),
+            _ptr(title_enc[i], ctypes.c_uint8), _ptr(truth_enc[i], ctypes.c_uint8), ctypes.c_uint8(int(space_code)))
+    return out

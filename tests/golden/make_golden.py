@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Golden-vector generator for the doppel-speller hot path (run in the BUILD container only).
+
+What this does
+--------------
+Imports the reference package from /root/reference (read-only) and runs ITS OWN function bodies
+(`fast_jaccard`, `fast_arg_top_k`, `MatchMaker`, `fast_levenshtein_ratio`, `construct_features`,
+`FeatureEngineering.encode_title` ...) on slices of the example data set that ships with the reference, then
+stores inputs + outputs at the two kernel boundaries as small .npz/.json fixtures next to this file.
+
+The reference needs `numba` and `Levenshtein`, neither of which is installed here (no network).  They are
+replaced, in THIS process only, by the tiny modules built in `_install_shims()`:
+
+* `numba.njit` / `numba.guvectorize` become pass-through decorators, so the decorated reference functions execute
+  as plain Python/NumPy.  Two pieces of numba *typing* are emulated because they change results:
+    - a Python `float` argument is widened to `np.float64` (numba types it float64; NumPy-2 would treat it as a
+      weak scalar and compute `match_maker.py:50` in float32);
+    - an explicit return type in a signature (`numba.uint8(...)`, `feature_engineering.py:25`) is applied as a cast.
+* `Levenshtein.ratio` raises: it is not on the hot path (only `common.py:161-167` uses it).
+
+Remaining differences between "reference source under NumPy" (what is captured here) and "reference source under
+numba 0.45" are listed in SURVEY.md section 8c and in oracle/README.md; every captured vector carries a
+`*_margin_ok` flag saying whether it is insensitive to those differences.  Nothing is written under /root/reference
+(PYTHONDONTWRITEBYTECODE is forced, the example CSVs are unpacked into a temp dir).
+
+Usage:  PYTHONHASHSEED=0 python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+if os.environ.get("PYTHONHASHSEED") != "0":
+    # vocabulary order is `enumerate(set(...))` (match_maker.py:145-147): pin it.
+    os.environ["PYTHONHASHSEED"] = "0"
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+    os.execv(sys.executable, [sys.executable] + sys.argv)
+
+import gzip
+import json
+import shutil
+import tempfile
+import types
+import warnings
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFERENCE = "/root/reference"
+
+
+def _install_shims():
+    numba = types.ModuleType("numba")
+
+    class _Type:
+        def __init__(self, np_type):
+            self.np_type = np_type
+
+        def __getitem__(self, item):  # numba.uint8[:]
+            return self
+
+        def __call__(self, *args):  # numba.uint8(numba.uint8[:], numba.uint8[:]) -> signature
+            return _Signature(self)
+
+    class _Signature:
+        def __init__(self, return_type):
+            self.return_type = return_type
+
+    for name in ("uint8", "uint32", "int32", "int64", "float32", "float64"):
+        setattr(numba, name, _Type(getattr(np, name)))
+
+    def njit(*args, **kwargs):
+        signature = args[0] if args and isinstance(args[0], _Signature) else None
+
+        def decorate(function):
+            def wrapper(*call_args):
+                call_args = [np.float64(a) if type(a) is float else a for a in call_args]
+                out = function(*call_args)
+                if signature is not None:
+                    with np.errstate(all="ignore"):
+                        out = signature.return_type.np_type(out)
+                return out
+
+            wrapper.__wrapped__ = function
+            wrapper.__name__ = function.__name__
+            return wrapper
+
+        if args and callable(args[0]) and not isinstance(args[0], _Signature):
+            return decorate(args[0])
+        return decorate
+
+    def guvectorize(signatures, layout, **kwargs):
+        def decorate(function):
+            def wrapper(*call_args):
+                *inputs, response = call_args
+                n = response.shape[0]
+                core_dims = [len(x.strip("()").split(",")) if x.strip("()") else 0
+                             for x in layout.split("->")[0].split("),(")]
+                for i in range(n):
+                    row = []
+                    for value, core in zip(inputs, core_dims):
+                        value = np.asarray(value)
+                        row.append(value[i] if value.ndim > core else (value[()] if core == 0 else value))
+                    function(*row, response[i])
+
+            wrapper.__wrapped__ = function
+            return wrapper
+
+        return decorate
+
+    typed = types.ModuleType("numba.typed")
+    typed.List = list
+    numba.njit = njit
+    numba.guvectorize = guvectorize
+    numba.typed = typed
+    sys.modules["numba"] = numba
+    sys.modules["numba.typed"] = typed
+
+    levenshtein = types.ModuleType("Levenshtein")
+
+    def ratio(*_):
+        raise NotImplementedError("python-Levenshtein is not available; not on the hot path")
+
+    levenshtein.ratio = ratio
+    sys.modules["Levenshtein"] = levenshtein
+
+
+def _stage_example_data(directory):
+    for name in ("example_truth", "example_test", "example_train"):
+        with gzip.open(f"{REFERENCE}/example_dataset/{name}.csv.gz", "rb") as source, \
+                open(f"{directory}/{name}.csv", "wb") as target:
+            shutil.copyfileobj(source, target)
+
+
+def main():
+    data_dir = tempfile.mkdtemp(prefix="ds_golden_")
+    _stage_example_data(data_dir)
+    os.environ["PROJECT_DATA_PATH"] = data_dir
+    _install_shims()
+    sys.path.insert(0, REFERENCE)
+    warnings.simplefilter("ignore")
+
+    import doppelspeller.settings as s
+    import doppelspeller.constants as c
+    from doppelspeller import common, match_maker, feature_engineering
+
+    truth_all = common.get_ground_truth()
+    test_all = common.get_test_data()
+
+    # ------------------------------------------------------------------ A. Levenshtein / encoding known answers
+    alphabet = f"{s.R_FILL_CHARACTER} abcdefghijklmnopqrstuvwxyz0123456789"
+    encoding = {ch: i for i, ch in enumerate(alphabet)}
+
+    def encode(text):
+        return np.array([encoding[ch] for ch in text], dtype=np.uint8)
+
+    pairs = [
+        ("coolblue bv", "coolblu bv"), ("abc", "abc"), ("abc", "xyz"), ("a", "ab"), ("kitten", "sitting"),
+        ("limited", "ltd"), ("systematica imnvestments services limited", "systematica investment services limited"),
+        ("feld s ullivan limited", "feld sullivan limited"), ("a" * 29 + "b" * 21, "a" * 29 + "c" * 21),
+        ("a", "a"), ("a", "b"), ("ab", "ba"), ("0", "0123456789"),
+    ]
+    rng = np.random.RandomState(12345)
+    truth_titles = list(truth_all[c.COLUMN_TRANSFORMED_TITLE])
+    test_titles = list(test_all[c.COLUMN_TRANSFORMED_TITLE])
+    for _ in range(400):
+        pairs.append((test_titles[rng.randint(len(test_titles))], truth_titles[rng.randint(len(truth_titles))]))
+    for _ in range(100):  # word-sized strings, as in the window loop of construct_features
+        a = rng.choice(truth_titles).split()[0]
+        b = rng.choice(test_titles).replace(" ", "")
+        start = rng.randint(max(1, len(b)))
+        pairs.append((b[start:start + len(a)] or "a", a))
+    lev = []
+    for a, b in pairs:
+        if len(a) + len(b) > 255:
+            continue
+        r1 = int(feature_engineering.fast_levenshtein_ratio(encode(a), encode(b)))
+        r2 = int(feature_engineering.fast_levenshtein_ratio(encode(b), encode(a)))
+        assert r1 == r2
+        lev.append({"a": a, "b": b, "ratio": r1})
+
+    fe = feature_engineering.FeatureEngineering.__new__(feature_engineering.FeatureEngineering)
+    fe.allowed_characters = alphabet
+    fe.encoding = encoding
+    fe.words_counter = common.get_words_counter(truth_all)
+    kat = {
+        "alphabet": alphabet,
+        "space_code": encoding[" "],
+        "levenshtein": lev,
+        "encode_title": {t: fe.encode_title(t)[:len(t) + 2].tolist() for t in ("coolblue bv 42", "a", test_titles[0])},
+        "n_grams": {t: sorted(common.get_n_grams(t, s.N_GRAMS)) for t in ("coolblue bv", "abc", "ab", test_titles[3])},
+        "transform_title": {t: common.transform_title(t) for t in
+                            ("Great Expectations Ministries", "Topdrill  Ltd.", "Ünïcode-Näme B.V.", "A")},
+        "truth_words_counts": {t: fe.get_truth_words_counts(t).tolist() for t in truth_titles[:5]},
+        "settings": {"N_GRAMS": s.N_GRAMS, "NUMBER_OF_WORDS_FEATURES": s.NUMBER_OF_WORDS_FEATURES,
+                     "MAX_CHARACTERS": int(s.MAX_CHARACTERS_ALLOWED_IN_THE_TITLE),
+                     "ENCODING_FLOAT_BUFFER_f32_bits": int(np.float32(s.ENCODING_FLOAT_BUFFER).view(np.uint32)),
+                     "FEATURES_COUNT": feature_engineering.FEATURES_COUNT},
+    }
+    with open(f"{HERE}/kat.json", "w") as handle:
+        json.dump(kat, handle, indent=1, sort_keys=True)
+
+    # ------------------------------------------------------------------ B. MatchMaker at the kernel boundary
+    n_truth, n_query = 5000, 200
+    truth = truth_all.iloc[:n_truth].reset_index(drop=True)
+    query = test_all.iloc[:n_query].reset_index(drop=True)
+    fixture = {}
+    for top_n in (10, 100):
+        mm = match_maker.MatchMaker(query.copy(), truth.copy(), top_n)
+        vocab = len(mm.n_grams_decoding)
+        if top_n == 10:
+            rowptr = np.zeros(vocab + 1, dtype=np.int64)
+            for g in range(vocab):
+                rowptr[g + 1] = rowptr[g] + len(mm.matrix_truth_non_zero_columns_and_values[g][0])
+            truth_idx = np.concatenate([np.asarray(x[0], dtype=np.int32)
+                                        for x in mm.matrix_truth_non_zero_columns_and_values])
+            idf32 = np.array([mm._get_idf_given_index(g) for g in range(vocab)], dtype=np.float32)
+            for g in range(vocab):  # the per-posting value array is the constant idf (match_maker.py:130)
+                values = mm.matrix_truth_non_zero_columns_and_values[g][1]
+                assert values.dtype == np.float32 and (values == idf32[g]).all()
+            q_rowptr = np.zeros(n_query + 1, dtype=np.int64)
+            for q in range(n_query):
+                q_rowptr[q + 1] = q_rowptr[q] + len(mm.matrix_non_zero_columns[q])
+            q_cols = np.concatenate([np.asarray(x, dtype=np.int32) for x in mm.matrix_non_zero_columns])
+            q_maxint = np.array([sum([mm._get_idf_given_index(r) for r in mm.matrix_non_zero_columns[q]])
+                                 for q in range(n_query)], dtype=np.float64)
+            fixture.update(rowptr=rowptr, truth_idx=truth_idx, idf32=idf32,
+                           sums32=mm.sums_matrix_truth.astype(np.float32), q_rowptr=q_rowptr, q_cols=q_cols,
+                           q_maxint=q_maxint, title_id=np.asarray(truth[c.COLUMN_TITLE_ID], dtype=np.int64),
+                           vocab=np.array(sorted(mm.n_grams_encoding, key=mm.n_grams_encoding.get)))
+            # full float64 jaccard arrays for a few queries (pins fast_jaccard on its own)
+            jac_rows = [0, 1, 2, 3, 50, 199]
+            jac = np.stack([match_maker.fast_jaccard(
+                mm.number_of_truth_titles, float(q_maxint[q]), mm.matrix_non_zero_columns[q],
+                mm.matrix_truth_non_zero_columns_and_values, mm.sums_matrix_truth) for q in jac_rows])
+            assert jac.dtype == np.float64
+            fixture.update(jac_rows=np.array(jac_rows), jac=jac)
+
+        rows = np.zeros((n_query, top_n), dtype=np.int32)
+        ids = np.zeros((n_query, top_n), dtype=np.int64)
+        margin_ok = np.zeros(n_query, dtype=bool)
+        for q in range(n_query):
+            jaccard = match_maker.fast_jaccard(
+                mm.number_of_truth_titles, float(fixture["q_maxint"][q]), mm.matrix_non_zero_columns[q],
+                mm.matrix_truth_non_zero_columns_and_values, mm.sums_matrix_truth)
+            top = match_maker.fast_arg_top_k(jaccard, top_n)
+            rows[q] = top
+            ids[q] = mm.get_closest_matches(q)
+            assert (ids[q] == fixture["title_id"][top]).all()
+            # margin: no value within 5e-7 of the select threshold, so the float32-vs-float64 subtraction at
+            # match_maker.py:70 (NumPy vs numba typing) cannot change the selected set.
+            positive = np.sort(jaccard[jaccard > 0])[::-1]
+            kth = np.float32(positive[top_n - 1]) if positive.shape[0] >= top_n else np.float32(0)
+            threshold = np.float64(kth) - np.float64(np.float32(s.ENCODING_FLOAT_BUFFER))
+            margin_ok[q] = np.abs(jaccard - threshold).min() > 5e-7
+        fixture[f"rows_k{top_n}"] = rows
+        fixture[f"ids_k{top_n}"] = ids
+        fixture[f"margin_ok_k{top_n}"] = margin_ok
+    np.savez_compressed(f"{HERE}/match_maker_5000x200.npz", **fixture)
+
+    # ------------------------------------------------------------------ C. construct_features at the kernel boundary
+    mm10_rows = fixture["rows_k10"]
+    pair_q, pair_t = [], []
+    for q in range(60):
+        for t in mm10_rows[q][:5]:
+            pair_q.append(q)
+            pair_t.append(int(t))
+    for _ in range(100):  # unrelated pairs too
+        pair_q.append(int(rng.randint(n_query)))
+        pair_t.append(int(rng.randint(n_truth)))
+    q_titles = list(query[c.COLUMN_TRANSFORMED_TITLE])
+    t_titles = list(truth[c.COLUMN_TRANSFORMED_TITLE])
+    fe.words_counter = common.get_words_counter(truth_all)  # counts over the whole 30k truth set
+    n_truth_titles = np.uint32(len(truth_all))
+    title_len = np.array([len(q_titles[q]) for q in pair_q], dtype=np.uint8)
+    truth_len = np.array([len(t_titles[t]) for t in pair_t], dtype=np.uint8)
+    title_enc = np.vstack([fe.encode_title(q_titles[q]) for q in pair_q])
+    truth_enc = np.vstack([fe.encode_title(t_titles[t]) for t in pair_t])
+    counts = np.vstack([fe.get_truth_words_counts(t_titles[t]) for t in pair_t])
+    features = np.zeros((len(pair_q), feature_engineering.FEATURES_COUNT), dtype=np.float32)
+    dummy = np.zeros((feature_engineering.FEATURES_COUNT,), dtype=np.uint8)
+    with np.errstate(all="ignore"):
+        feature_engineering.construct_features(title_len, truth_len, title_enc, truth_enc, counts,
+                                               np.uint8(encoding[" "]), n_truth_titles, dummy, features)
+    np.savez_compressed(
+        f"{HERE}/construct_features_400.npz", title_len=title_len, truth_len=truth_len, title_enc=title_enc,
+        truth_enc=truth_enc, counts=counts, space_code=np.uint8(encoding[" "]), n_truth=n_truth_titles,
+        features=features, titles=np.array([q_titles[q] for q in pair_q]),
+        truth_titles=np.array([t_titles[t] for t in pair_t]))
+
+    shutil.rmtree(data_dir)
+    print("levenshtein KATs:", len(lev))
+    print("match_maker margin_ok k10/k100:", int(fixture["margin_ok_k10"].sum()), int(fixture["margin_ok_k100"].sum()),
+          "of", n_query)
+    print("construct_features pairs:", features.shape, "NaNs:", int(np.isnan(features).sum()))
+    print("first query top-10 ids:", fixture["ids_k10"][0].tolist())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""The CPU oracle (oracle/doppel_oracle.c) against the golden vectors captured from the reference's own function
+bodies (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+
+
+def _encode(kat, text):
+    table = {ch: i for i, ch in enumerate(kat["alphabet"])}
+    return np.array([table[ch] for ch in text], dtype=np.uint8)
+
+
+def test_levenshtein_known_answers(oracle, golden_kat):
+    for typing in ("numba", "numpy"):
+        for case in golden_kat["levenshtein"]:
+            a, b = _encode(golden_kat, case["a"]), _encode(golden_kat, case["b"])
+            assert oracle.levenshtein_ratio(a, b, typing) == case["ratio"], (case, typing)
+            assert oracle.levenshtein_ratio(b, a, typing) == case["ratio"], (case, typing)
+
+
+def test_levenshtein_survey_values(oracle, golden_kat):
+    # SURVEY.md section 8c known answers (captured by import in the survey session)
+    expected = {("coolblue bv", "coolblu bv"): 95, ("abc", "abc"): 100, ("abc", "xyz"): 0, ("a", "ab"): 66,
+                ("kitten", "sitting"): 61, ("limited", "ltd"): 60,
+                ("systematica imnvestments services limited", "systematica investment services limited"): 97,
+                ("feld s ullivan limited", "feld sullivan limited"): 97,
+                ("a" * 29 + "b" * 21, "a" * 29 + "c" * 21): 57}  # hazard point (58,100): strict IEEE -> 57
+    for (a, b), ratio in expected.items():
+        assert oracle.levenshtein_ratio(_encode(golden_kat, a), _encode(golden_kat, b)) == ratio
+
+
+def test_fast_jaccard_bit_exact(oracle, golden_match_maker):
+    g = golden_match_maker
+    for row, expected in zip(g["jac_rows"], g["jac"]):
+        columns = g["q_cols"][g["q_rowptr"][row]:g["q_rowptr"][row + 1]]
+        got = oracle.fast_jaccard(g["q_maxint"][row], columns, g["rowptr"], g["truth_idx"], g["idf32"], g["sums32"])
+        assert got.dtype == np.float64
+        assert np.array_equal(got.view(np.uint64), expected.view(np.uint64))
+
+
+def test_fast_arg_top_k_on_captured_jaccard(oracle, golden_match_maker):
+    g = golden_match_maker
+    for row, jaccard in zip(g["jac_rows"], g["jac"]):
+        for k in (10, 100):
+            got = oracle.fast_arg_top_k(jaccard, k, "numpy")
+            assert np.array_equal(got, g[f"rows_k{k}"][row])
+            if g[f"margin_ok_k{k}"][row]:
+                assert np.array_equal(oracle.fast_arg_top_k(jaccard, k, "numba"), g[f"rows_k{k}"][row])
+
+
+def test_jaccard_topk_batch(oracle, golden_match_maker):
+    g = golden_match_maker
+    for k in (10, 100):
+        numpy_typed = oracle.jaccard_topk(g["rowptr"], g["truth_idx"], g["idf32"], g["sums32"], g["q_rowptr"],
+                                          g["q_cols"], g["q_maxint"], k, "numpy")
+        assert np.array_equal(numpy_typed, g[f"rows_k{k}"])  # every vector, captured typing
+        numba_typed = oracle.jaccard_topk(g["rowptr"], g["truth_idx"], g["idf32"], g["sums32"], g["q_rowptr"],
+                                          g["q_cols"], g["q_maxint"], k, "numba")
+        ok = g[f"margin_ok_k{k}"]
+        assert ok.sum() >= 0.95 * ok.shape[0]
+        assert np.array_equal(numba_typed[ok], g[f"rows_k{k}"][ok])  # specification typing, margin-checked vectors
+        assert np.array_equal(g["title_id"][numba_typed[ok]], g[f"ids_k{k}"][ok])
+
+
+def test_jaccard_topk_raises_when_fewer_than_k(oracle, golden_match_maker):
+    g = golden_match_maker
+    import pytest
+    with pytest.raises(Exception, match="top_matches.shape"):
+        oracle.jaccard_topk(g["rowptr"], g["truth_idx"], g["idf32"], g["sums32"], g["q_rowptr"][:2], g["q_cols"],
+                            g["q_maxint"][:1], g["sums32"].shape[0] + 1)
+
+
+def test_construct_features_bit_exact(oracle, golden_features):
+    g = golden_features
+    expected = g["features"]
+    got = oracle.construct_features(g["title_len"], g["truth_len"], g["title_enc"], g["truth_enc"], g["counts"],
+                                    g["space_code"], g["n_truth"], "numpy")
+    assert np.array_equal(got.view(np.uint32), expected.view(np.uint32))  # NaN pattern included
+    spec = oracle.construct_features(g["title_len"], g["truth_len"], g["title_enc"], g["truth_enc"], g["counts"],
+                                     g["space_code"], g["n_truth"], "numba")
+    # numba typing differs only in the 15 rank features (float64 vs float32 arithmetic), by at most one ulp
+    assert np.array_equal(spec[:, :51].view(np.uint32), expected[:, :51].view(np.uint32))
+    ranks_spec, ranks_np = spec[:, 51:], expected[:, 51:]
+    assert np.array_equal(np.isnan(ranks_spec), np.isnan(ranks_np))
+    different = (ranks_spec.view(np.uint32) != ranks_np.view(np.uint32)) & ~np.isnan(ranks_np)
+    assert different.mean() < 0.05
+    assert np.all(np.abs(ranks_spec.view(np.int32).astype(np.int64) - ranks_np.view(np.int32))[~np.isnan(ranks_np)] <= 1)
+
+
+def test_construct_features_survey_example(oracle, golden_kat):
+    # q='systematica imnvestments services limited', t='maxima technologies nl bv'
+    q, t = "systematica imnvestments services limited", "maxima technologies nl bv"
+    enc = lambda text: np.pad(_encode(golden_kat, text), (0, 255 - len(text)))[None, :]
+    counts = np.zeros((1, 15), dtype=np.uint32)
+    counts[0, :4] = [1, 306, 51, 4923]
+    with np.errstate(all="ignore"):
+        out = oracle.construct_features([len(q)], [len(t)], enc(q), enc(t), counts, 1, 30000)[0]
+    assert out[:6].tolist() == [41, 25, 4, 4, 39, 56]
+    assert out[6:10].tolist() == [66, 41, 50, 50] and np.isnan(out[10:21]).all()
+    assert out[21:25].tolist() == [6, 12, 2, 2]
+    assert np.allclose(out[36:40], [10.309, 4.5854, 6.3771, 1.8073], atol=1e-4)
+    assert np.allclose(out[51:55], [1, 2.4309, 1.983, 3.1254], atol=1e-4)
