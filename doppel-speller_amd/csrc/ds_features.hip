@@ -1,0 +1,493 @@
+// fast_levenshtein_ratio + construct_features (doppelspeller/feature_engineering.py:25-169) on gfx950.
+//
+// Reference semantics: the DP of :39-61 has insert/delete cost 1 and substitute cost 2, i.e. it computes the indel
+// distance d = L - 2*LCS(a, b) with L = len(a)+len(b); the returned value is uint8(((L - d) / L) * 100) evaluated in
+// float64 in source order (:63).  The DP matrix is uint8 (:42): as long as L <= 255 no cell can wrap and the
+// identity is exact; beyond that the stores wrap modulo 256 and only a literal emulation reproduces the result.
+//
+// One wavefront (64 lanes) per (title, truth title) pair:
+//   * LCS by the bit-parallel recurrence V' = (V + (V & M[c])) | (V & ~M[c]) over a 64-bit column vector (pattern =
+//     the shorter string, <= 64 chars; M[c] = match mask of the pattern for character code c, built in LDS with one
+//     ds_or per pattern character);
+//   * the word loop of :128-155 maps one window start per lane: every lane runs the recurrence for its window
+//     against the current truth word, then a wave max-reduction keeps the first best window (:147-149);
+//   * pairs that do not fit (L > 255, pattern > 64 chars, character code >= 64) take the literal path: an
+//     anti-diagonal DP with uint8 wrap-around, three diagonals staged in LDS, 64 cells per step.
+// All strings, masks and the reconstructed title live in LDS; HBM traffic is the title bytes in and 264 B out.
+#include <cmath>
+
+#include "ds_common.h"
+
+namespace ds {
+
+constexpr int kFeatWaves = 4;
+constexpr int kReconCap = 288;  // 1 + sum(word lengths) + 15 separators <= 1 + 255 + 16
+
+struct FeatureArgs {
+    const uint8_t *q_enc;
+    const uint8_t *q_len;
+    const uint8_t *t_enc;
+    const uint8_t *t_len;
+    const uint32_t *t_counts;
+    const int32_t *pair_q;  // nullable
+    const int32_t *pair_t;  // nullable
+    float *out;
+    int64_t q_stride, t_stride;
+    int64_t n_q, n_t;       // table sizes (bounds for indexes)
+    int64_t n;              // pairs
+    int64_t q_first;
+    int32_t k;              // > 0: pair i belongs to query q_first + i / k (when pair_q is null)
+    uint32_t n_truth;
+    uint8_t space_code;
+};
+
+struct WaveScratch {
+    unsigned long long masks[64];
+    uint8_t q[256];
+    uint8_t t[256];
+    uint8_t qw[256];
+    uint8_t recon[kReconCap];
+    uint8_t diag[3][kReconCap];
+    float features[72];
+    int32_t word_begin[16];
+    int32_t word_len[16];
+};
+
+__device__ __forceinline__ uint8_t ratio_from_lcs(int lcs, int total_length)
+{
+    if (total_length == 0) return 0;  // 0/0 in the reference; unreachable from its callers
+    const double ratio = (static_cast<double>(2 * lcs) / static_cast<double>(total_length)) * 100.0;  // :63
+    return static_cast<uint8_t>(ratio);
+}
+
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// Build M[c] for pattern[0..m) (m <= 64, all codes < 64) in scratch.masks.  All 64 lanes participate.
+__device__ __forceinline__ void build_masks(WaveScratch &w, const uint8_t *pattern, int m, int lane)
+{
+    w.masks[lane] = 0ull;
+    wave_sync();
+    if (lane < m) atomicOr(&w.masks[pattern[lane]], 1ull << lane);
+    wave_sync();
+}
+
+// LCS length of text[0..n) against the pattern whose masks are in scratch.masks (pattern length m <= 64).
+__device__ __forceinline__ int lcs_bitparallel(const WaveScratch &w, const uint8_t *text, int n, int m)
+{
+    unsigned long long v = ~0ull;
+    for (int i = 0; i < n; ++i) {
+        const unsigned long long match = w.masks[text[i]];
+        const unsigned long long u = v & match;
+        v = (v + u) | (v & ~match);
+    }
+    const unsigned long long valid = m >= 64 ? ~0ull : ((1ull << m) - 1ull);
+    return __popcll(~v & valid);
+}
+
+// Literal fast_levenshtein_ratio (:25-63) with uint8 wrap-around, cooperative over the wave; a/b in LDS.
+__device__ uint8_t levenshtein_literal(WaveScratch &w, const uint8_t *a, int la, const uint8_t *b, int lb, int lane)
+{
+    const int total_length = la + lb;
+    if (la > lb) {  // :35-37
+        const uint8_t *ts = a; a = b; b = ts;
+        const int tl = la; la = lb; lb = tl;
+    }
+    // diagonal d holds matrix[x][d - x] at index x, x in [max(0, d - lb), min(la, d)]
+    for (int d = 0; d <= la + lb; ++d) {
+        uint8_t *current = w.diag[d % 3];
+        const uint8_t *previous = w.diag[(d + 2) % 3];
+        const uint8_t *before = w.diag[(d + 1) % 3];
+        const int x_low = d > lb ? d - lb : 0;
+        const int x_high = d < la ? d : la;
+        for (int x = x_low + lane; x <= x_high; x += 64) {
+            const int y = d - x;
+            int value;
+            if (x == 0) value = y;            // :45-46
+            else if (y == 0) value = x;       // :43-44
+            else {
+                const int up = previous[x - 1] + 1;                                   // matrix[x-1, y] + 1
+                const int diagonal = before[x - 1] + (a[x - 1] == b[y - 1] ? 0 : 2);  // matrix[x-1, y-1] (+2)
+                const int left = previous[x] + 1;                                     // matrix[x, y-1] + 1
+                value = min(up, min(diagonal, left));                                 // int64 min, then uint8 store
+            }
+            current[x] = static_cast<uint8_t>(value);
+        }
+        wave_sync();
+    }
+    if (total_length == 0) return 0;
+    const int distance = w.diag[(la + lb) % 3][la];
+    const double ratio = (static_cast<double>(total_length - distance) / static_cast<double>(total_length)) * 100.0;
+    return static_cast<uint8_t>(ratio);
+}
+
+__device__ __forceinline__ bool codes_below_64(const uint8_t *s, int n, int lane)
+{
+    bool ok = true;
+    for (int i = lane; i < n; i += 64) ok &= s[i] < 64;
+    return __all(ok);
+}
+
+// fast_levenshtein_ratio of two LDS strings, wave-uniform result.  `small_alphabet` = every code of both < 64.
+__device__ uint8_t levenshtein_wave(WaveScratch &w, const uint8_t *a, int la, const uint8_t *b, int lb, int lane,
+                                    bool small_alphabet)
+{
+    const int shorter = la < lb ? la : lb;
+    if (small_alphabet && la + lb <= 255 && shorter <= 64) {
+        const uint8_t *pattern = la <= lb ? a : b;
+        const uint8_t *text = la <= lb ? b : a;
+        build_masks(w, pattern, shorter, lane);
+        const int lcs = lcs_bitparallel(w, text, la + lb - shorter, shorter);
+        return ratio_from_lcs(lcs, la + lb);
+    }
+    return levenshtein_literal(w, a, la, b, lb, lane);
+}
+
+__global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(FeatureArgs a)
+{
+    __shared__ WaveScratch scratch[kFeatWaves];
+    const int lane = threadIdx.x & 63;
+    WaveScratch &w = scratch[threadIdx.x >> 6];
+    const int64_t wave_global = static_cast<int64_t>(blockIdx.x) * kFeatWaves + (threadIdx.x >> 6);
+    const int64_t wave_count = static_cast<int64_t>(gridDim.x) * kFeatWaves;
+    const uint8_t space = a.space_code;
+    const float nan = __uint_as_float(0x7fc00000u);
+
+    for (int64_t pair = wave_global; pair < a.n; pair += wave_count) {
+        float *out = a.out + pair * DS_FEATURES_COUNT;
+        const int64_t qi = a.pair_q ? a.pair_q[pair] : (a.k > 0 ? a.q_first + pair / a.k : pair);
+        const int64_t ti = a.pair_t ? a.pair_t[pair] : pair;
+        if (qi < 0 || qi >= a.n_q || ti < 0 || ti >= a.n_t) {  // e.g. a -1 row of a failed top-k
+            out[lane] = nan;
+            if (lane < 2) out[64 + lane] = nan;
+            continue;
+        }
+        const int lq = a.q_len[qi], lt = a.t_len[ti];                                      // :101-102
+        const uint8_t *gq = a.q_enc + qi * a.q_stride;
+        const uint8_t *gt = a.t_enc + ti * a.t_stride;
+        wave_sync();
+        // stage both strings; count spaces; squeeze the spaces out of the title (:104-108)
+        int spaces_q = 0, spaces_t = 0, lw = 0;
+        for (int base = 0; base < 256; base += 64) {
+            const int i = base + lane;
+            const uint8_t cq = i < lq ? gq[i] : 0;
+            const uint8_t ct = i < lt ? gt[i] : 0;
+            w.q[i] = cq;
+            w.t[i] = ct;
+            const bool is_char = i < lq && cq != space;
+            const unsigned long long keep = __ballot(is_char);
+            if (is_char) w.qw[lw + __popcll(keep & ((1ull << lane) - 1ull))] = cq;
+            lw += __popcll(keep);
+            spaces_q += __popcll(__ballot(i < lq && cq == space));
+            spaces_t += __popcll(__ballot(i < lt && ct == space));
+        }
+        wave_sync();
+        const int title_words = spaces_q + 1, truth_words = spaces_t + 1;
+        const bool small_alphabet = codes_below_64(w.q, lq, lane) && codes_below_64(w.t, lt, lane);
+
+        // truth word boundaries: positions of the spaces of truth + [space], first 15 (:110-114)
+        int n_words = 0;
+        {
+            int previous_end = 0;  // start of the current word
+            for (int base = 0; base <= lt && n_words < DS_WORDS; base += 64) {
+                const int i = base + lane;
+                const bool is_space = i <= lt && (i == lt || w.t[i] == space);
+                unsigned long long votes = __ballot(is_space);
+                while (votes && n_words < DS_WORDS) {
+                    const int position = base + __ffsll(votes) - 1;
+                    if (lane == 0) {
+                        w.word_begin[n_words] = previous_end;
+                        w.word_len[n_words] = position - previous_end;
+                    }
+                    previous_end = position + 1;
+                    ++n_words;
+                    votes &= votes - 1ull;
+                }
+            }
+        }
+        wave_sync();
+
+        const uint8_t lev_ratio = levenshtein_wave(w, w.q, lq, w.t, lt, lane, small_alphabet);  // :106
+
+        // ---- truth words loop (:128-155)
+        if (lane < DS_WORDS) {
+            w.features[6 + lane] = nan;
+            w.features[6 + DS_WORDS + lane] = nan;
+            w.features[6 + 2 * DS_WORDS + lane] = nan;
+        }
+        int lr = 0;
+        if (lane == 0) w.recon[0] = space;  // :115
+        lr = 1;
+        for (int word = 0; word < n_words; ++word) {
+            const int begin = w.word_begin[word], length = w.word_len[word];
+            const uint8_t *truth_word = w.t + begin;
+            int best_key = 0;  // (ratio << 8) | (255 - start): larger ratio first, then the earliest window
+            if (length > 0 && lw > 0) {
+                const bool fast = small_alphabet && length <= 64;
+                if (fast) build_masks(w, truth_word, length, lane);
+                for (int base = 0; base < lw; base += 64) {
+                    const int start = base + lane;
+                    int ratio = 0;
+                    if (fast) {
+                        if (start < lw) {
+                            const int window = min(length, lw - start);                      // :142
+                            const int lcs = lcs_bitparallel(w, w.qw + start, window, length);
+                            ratio = ratio_from_lcs(lcs, window + length);                    // :146
+                        }
+                    } else {
+                        for (int s = base; s < min(base + 64, lw); ++s) {                    // literal, one window at a time
+                            const int window = min(length, lw - s);
+                            const uint8_t r = levenshtein_literal(w, w.qw + s, window, truth_word, length, lane);
+                            if (s == start) ratio = r;
+                        }
+                    }
+                    int key = start < lw ? ((ratio << 8) | (255 - start)) : 0;
+                    for (int offset = 32; offset > 0; offset >>= 1) key = max(key, __shfl_xor(key, offset));
+                    best_key = max(best_key, key);
+                }
+            }
+            const int best_ratio = best_key >> 8;                                             // :147-149
+            int match_start = 0, match_length = 1;
+            const bool matched = best_ratio > 0;
+            if (matched) {
+                match_start = 255 - (best_key & 255);
+                match_length = min(length, lw - match_start);
+            }
+            // reconstructed += best_match + [space]  (:154-155); best_match = [space] when nothing matched (:140)
+            for (int i = lane; i < match_length; i += 64) w.recon[lr + i] = matched ? w.qw[match_start + i] : space;
+            if (lane == 0) {
+                w.recon[lr + match_length] = space;
+                w.features[6 + word] = static_cast<float>(best_ratio);                        // :151
+                w.features[6 + DS_WORDS + word] = static_cast<float>(length);                 // :152
+                w.features[6 + 2 * DS_WORDS + word] = static_cast<float>(
+                    log(static_cast<double>(a.n_truth) / static_cast<double>(a.t_counts[ti * DS_WORDS + word])));  // :153
+            }
+            lr += match_length + 1;
+            wave_sync();
+        }
+
+        // :161-162  strip the first and the last space
+        const uint8_t recon_ratio = levenshtein_wave(w, w.recon + 1, lr - 2, w.t, lt, lane, small_alphabet);
+
+        // :158  ranks = 1 + (nanmax(idf_s) - idf_s) / truth_number_of_words   (float32 difference, float64 quotient)
+        float idf = lane < DS_WORDS ? w.features[6 + 2 * DS_WORDS + lane] : nan;
+        float maximum = idf;
+        for (int offset = 8; offset > 0; offset >>= 1) {
+            const float other = __shfl_xor(maximum, offset, 16);
+            maximum = (other != other) ? maximum : ((maximum != maximum || other > maximum) ? other : maximum);
+        }
+        if (lane < DS_WORDS) {
+            const float difference = maximum - idf;
+            w.features[6 + 3 * DS_WORDS + lane] =
+                static_cast<float>(1.0 + static_cast<double>(difference) / static_cast<double>(truth_words));
+        }
+        if (lane == 0) {  // :164-167
+            w.features[0] = static_cast<float>(lq);
+            w.features[1] = static_cast<float>(lt);
+            w.features[2] = static_cast<float>(title_words);
+            w.features[3] = static_cast<float>(truth_words);
+            w.features[4] = static_cast<float>(lev_ratio);
+            w.features[5] = static_cast<float>(recon_ratio);
+        }
+        wave_sync();
+        out[lane] = w.features[lane];
+        if (lane < 2) out[64 + lane] = w.features[64 + lane];
+    }
+}
+
+// fast_levenshtein_ratio for independent pairs (test / cross-check entry point); one wave per pair.
+struct LevArgs {
+    const uint8_t *a_chars;
+    const int64_t *a_off;
+    const uint8_t *b_chars;
+    const int64_t *b_off;
+    uint8_t *out;
+    int64_t n;
+    int32_t method;
+};
+
+__global__ __launch_bounds__(kFeatWaves * 64) void ds_levenshtein_kernel(LevArgs a)
+{
+    __shared__ WaveScratch scratch[kFeatWaves];
+    const int lane = threadIdx.x & 63;
+    WaveScratch &w = scratch[threadIdx.x >> 6];
+    const int64_t wave_global = static_cast<int64_t>(blockIdx.x) * kFeatWaves + (threadIdx.x >> 6);
+    const int64_t wave_count = static_cast<int64_t>(gridDim.x) * kFeatWaves;
+    for (int64_t pair = wave_global; pair < a.n; pair += wave_count) {
+        const int64_t a0 = a.a_off[pair], b0 = a.b_off[pair];
+        const int la = static_cast<int>(a.a_off[pair + 1] - a0), lb = static_cast<int>(a.b_off[pair + 1] - b0);
+        wave_sync();
+        // strings up to kReconCap-1 / 255 chars: a -> recon buffer, b -> t buffer
+        for (int i = lane; i < la; i += 64) w.recon[i] = a.a_chars[a0 + i];
+        for (int i = lane; i < lb; i += 64) w.t[i] = a.b_chars[b0 + i];
+        wave_sync();
+        uint8_t ratio;
+        if (a.method == 0) {
+            const bool small_alphabet = codes_below_64(w.recon, la, lane) && codes_below_64(w.t, lb, lane);
+            ratio = levenshtein_wave(w, w.recon, la, w.t, lb, lane, small_alphabet);
+        } else {
+            ratio = levenshtein_literal(w, w.recon, la, w.t, lb, lane);
+        }
+        if (lane == 0) a.out[pair] = ratio;
+    }
+}
+
+static int launch_features(const FeatureArgs &args, int device, hipStream_t stream)
+{
+    if (args.n == 0) return DS_OK;
+    (void)device;
+    const int64_t blocks_needed = (args.n + kFeatWaves - 1) / kFeatWaves;
+    const int grid = static_cast<int>(std::min<int64_t>(blocks_needed, 256 * 32));
+    hipLaunchKernelGGL(ds_construct_features_kernel, dim3(grid), dim3(kFeatWaves * 64), 0, stream, args);
+    DS_HIP(hipGetLastError());
+    return DS_OK;
+}
+
+}  // namespace ds
+
+extern "C" {
+
+int ds_construct_features(const uint8_t *q_len, const uint8_t *t_len, const uint8_t *q_enc, const uint8_t *t_enc,
+                          const uint32_t *t_word_counts, uint8_t space_code, uint32_t n_truth, int64_t n,
+                          int64_t stride, int device, float *out)
+{
+    DS_REQUIRE(n >= 0, "ds_construct_features: negative pair count");
+    if (n == 0) return DS_OK;
+    DS_REQUIRE(q_len && t_len && q_enc && t_enc && t_word_counts && out, "ds_construct_features: null pointer");
+    DS_REQUIRE(stride >= 1, "ds_construct_features: stride must be positive");
+    for (int64_t i = 0; i < n; ++i)
+        DS_REQUIRE(q_len[i] <= stride && t_len[i] <= stride,
+                   "ds_construct_features: length of pair %lld exceeds the row stride %lld", (long long)i,
+                   (long long)stride);
+    DS_HIP(hipSetDevice(device));
+    ds::DeviceBuffer<uint8_t> d_qlen, d_tlen, d_qenc, d_tenc;
+    ds::DeviceBuffer<uint32_t> d_counts;
+    ds::DeviceBuffer<float> d_out;
+    int status = d_qlen.upload(q_len, n);
+    if (status == DS_OK) status = d_tlen.upload(t_len, n);
+    if (status == DS_OK) status = d_qenc.upload(q_enc, static_cast<size_t>(n * stride));
+    if (status == DS_OK) status = d_tenc.upload(t_enc, static_cast<size_t>(n * stride));
+    if (status == DS_OK) status = d_counts.upload(t_word_counts, static_cast<size_t>(n) * DS_WORDS);
+    if (status == DS_OK) status = d_out.allocate(static_cast<size_t>(n) * DS_FEATURES_COUNT);
+    if (status != DS_OK) return status;
+    ds::FeatureArgs args{};
+    args.q_enc = d_qenc.ptr; args.q_len = d_qlen.ptr; args.t_enc = d_tenc.ptr; args.t_len = d_tlen.ptr;
+    args.t_counts = d_counts.ptr; args.pair_q = nullptr; args.pair_t = nullptr; args.out = d_out.ptr;
+    args.q_stride = stride; args.t_stride = stride; args.n_q = n; args.n_t = n; args.n = n; args.q_first = 0;
+    args.k = 0; args.n_truth = n_truth; args.space_code = space_code;
+    status = ds::launch_features(args, device, nullptr);
+    if (status != DS_OK) return status;
+    DS_HIP(hipMemcpy(out, d_out.ptr, d_out.bytes(), hipMemcpyDeviceToHost));
+    return DS_OK;
+}
+
+int ds_titles_create(const uint8_t *enc, int64_t stride, const uint8_t *len, const uint32_t *word_counts, int64_t n,
+                     int device, ds_titles **out)
+{
+    DS_REQUIRE(out != nullptr, "ds_titles_create: out is null");
+    *out = nullptr;
+    DS_REQUIRE(enc && len && n > 0 && stride >= 1, "ds_titles_create: bad arguments");
+    for (int64_t i = 0; i < n; ++i)
+        DS_REQUIRE(len[i] <= stride, "ds_titles_create: length of row %lld exceeds the stride", (long long)i);
+    DS_HIP(hipSetDevice(device));
+    ds_titles *titles = new ds_titles();
+    titles->device = device;
+    titles->n = n;
+    titles->stride = stride;
+    titles->has_counts = word_counts != nullptr;
+    int status = titles->enc.upload(enc, static_cast<size_t>(n * stride));
+    if (status == DS_OK) status = titles->len.upload(len, static_cast<size_t>(n));
+    if (status == DS_OK && word_counts) status = titles->counts.upload(word_counts, static_cast<size_t>(n) * DS_WORDS);
+    if (status != DS_OK) {
+        delete titles;
+        return status;
+    }
+    *out = titles;
+    return DS_OK;
+}
+
+void ds_titles_destroy(ds_titles *titles)
+{
+    if (!titles) return;
+    (void)hipSetDevice(titles->device);
+    delete titles;
+}
+
+int ds_construct_features_indexed_device(ds_titles *queries, ds_titles *truth, const int32_t *d_pair_q,
+                                         const int32_t *d_pair_t, int64_t q_first, int32_t k, uint8_t space_code,
+                                         uint32_t n_truth, int64_t n, float *d_out, void *stream)
+{
+    DS_REQUIRE(queries && truth, "ds_construct_features_indexed: null table");
+    DS_REQUIRE(truth->has_counts, "ds_construct_features_indexed: the truth table has no word counts");
+    DS_REQUIRE(queries->device == truth->device, "ds_construct_features_indexed: tables on different devices");
+    DS_REQUIRE(n >= 0, "ds_construct_features_indexed: negative pair count");
+    if (n == 0) return DS_OK;
+    DS_REQUIRE(d_pair_t && d_out, "ds_construct_features_indexed: null pointer");
+    DS_REQUIRE(d_pair_q || k > 0, "ds_construct_features_indexed: need pair_q or k > 0");
+    DS_HIP(hipSetDevice(truth->device));
+    ds::FeatureArgs args{};
+    args.q_enc = queries->enc.ptr; args.q_len = queries->len.ptr; args.t_enc = truth->enc.ptr;
+    args.t_len = truth->len.ptr; args.t_counts = truth->counts.ptr; args.pair_q = d_pair_q; args.pair_t = d_pair_t;
+    args.out = d_out; args.q_stride = queries->stride; args.t_stride = truth->stride; args.n_q = queries->n;
+    args.n_t = truth->n; args.n = n; args.q_first = q_first; args.k = d_pair_q ? 0 : k; args.n_truth = n_truth;
+    args.space_code = space_code;
+    return ds::launch_features(args, truth->device, static_cast<hipStream_t>(stream));
+}
+
+int ds_construct_features_indexed(ds_titles *queries, ds_titles *truth, const int32_t *pair_q, const int32_t *pair_t,
+                                  uint8_t space_code, uint32_t n_truth, int64_t n, float *out)
+{
+    DS_REQUIRE(queries && truth, "ds_construct_features_indexed: null table");
+    DS_REQUIRE(n >= 0, "ds_construct_features_indexed: negative pair count");
+    if (n == 0) return DS_OK;
+    DS_REQUIRE(pair_q && pair_t && out, "ds_construct_features_indexed: null pointer");
+    for (int64_t i = 0; i < n; ++i)
+        DS_REQUIRE(pair_q[i] >= 0 && pair_q[i] < queries->n && pair_t[i] >= 0 && pair_t[i] < truth->n,
+                   "ds_construct_features_indexed: pair %lld indexes outside the tables", (long long)i);
+    DS_HIP(hipSetDevice(truth->device));
+    ds::DeviceBuffer<int32_t> d_q, d_t;
+    ds::DeviceBuffer<float> d_out;
+    int status = d_q.upload(pair_q, static_cast<size_t>(n));
+    if (status == DS_OK) status = d_t.upload(pair_t, static_cast<size_t>(n));
+    if (status == DS_OK) status = d_out.allocate(static_cast<size_t>(n) * DS_FEATURES_COUNT);
+    if (status != DS_OK) return status;
+    status = ds_construct_features_indexed_device(queries, truth, d_q.ptr, d_t.ptr, 0, 0, space_code, n_truth, n,
+                                                  d_out.ptr, nullptr);
+    if (status != DS_OK) return status;
+    DS_HIP(hipMemcpy(out, d_out.ptr, d_out.bytes(), hipMemcpyDeviceToHost));
+    return DS_OK;
+}
+
+int ds_levenshtein_ratio_batch(const uint8_t *a_chars, const int64_t *a_off, const uint8_t *b_chars,
+                               const int64_t *b_off, int64_t n, int method, int device, uint8_t *out)
+{
+    DS_REQUIRE(n >= 0, "ds_levenshtein_ratio_batch: negative pair count");
+    if (n == 0) return DS_OK;
+    DS_REQUIRE(a_off && b_off && out, "ds_levenshtein_ratio_batch: null pointer");
+    DS_REQUIRE(method == 0 || method == 1, "ds_levenshtein_ratio_batch: method must be 0 or 1");
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t la = a_off[i + 1] - a_off[i], lb = b_off[i + 1] - b_off[i];
+        DS_REQUIRE(la >= 0 && la < ds::kReconCap && lb >= 0 && lb <= DS_MAX_CHARS,
+                   "ds_levenshtein_ratio_batch: pair %lld: lengths (%lld, %lld) outside (<=287, <=255)",
+                   (long long)i, (long long)la, (long long)lb);
+    }
+    DS_HIP(hipSetDevice(device));
+    ds::DeviceBuffer<uint8_t> d_a, d_b, d_out;
+    ds::DeviceBuffer<int64_t> d_aoff, d_boff;
+    int status = d_a.upload(a_chars, static_cast<size_t>(a_off[n] > 0 ? a_off[n] : 0));
+    if (status == DS_OK && a_off[n] == 0) status = d_a.allocate(1);
+    if (status == DS_OK) status = d_b.upload(b_chars, static_cast<size_t>(b_off[n] > 0 ? b_off[n] : 0));
+    if (status == DS_OK && b_off[n] == 0) status = d_b.allocate(1);
+    if (status == DS_OK) status = d_aoff.upload(a_off, static_cast<size_t>(n + 1));
+    if (status == DS_OK) status = d_boff.upload(b_off, static_cast<size_t>(n + 1));
+    if (status == DS_OK) status = d_out.allocate(static_cast<size_t>(n));
+    if (status != DS_OK) return status;
+    ds::LevArgs args{d_a.ptr, d_aoff.ptr, d_b.ptr, d_boff.ptr, d_out.ptr, n, method};
+    const int64_t blocks_needed = (n + ds::kFeatWaves - 1) / ds::kFeatWaves;
+    const int grid = static_cast<int>(std::min<int64_t>(blocks_needed, 256 * 32));
+    hipLaunchKernelGGL(ds::ds_levenshtein_kernel, dim3(grid), dim3(ds::kFeatWaves * 64), 0, nullptr, args);
+    DS_HIP(hipGetLastError());
+    DS_HIP(hipMemcpy(out, d_out.ptr, static_cast<size_t>(n), hipMemcpyDeviceToHost));
+    return DS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,268 @@
+// Library plumbing: error reporting, device memory, timers, and the construction of the tiled truth index in HBM.
+#include <algorithm>
+#include <cstring>
+
+#include "ds_common.h"
+
+namespace ds {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *format, ...)
+{
+    char buffer[1024];
+    va_list args;
+    va_start(args, format);
+    vsnprintf(buffer, sizeof(buffer), format, args);
+    va_end(args);
+    g_last_error = buffer;
+}
+
+int hip_failed(hipError_t error, const char *what, const char *file, int line)
+{
+    set_error("HIP error %d (%s) at %s:%d in %s", static_cast<int>(error), hipGetErrorString(error), file, line, what);
+    return DS_E_HIP;
+}
+
+}  // namespace ds
+
+extern "C" {
+
+const char *ds_last_error(void) { return ds::g_last_error.c_str(); }
+
+int ds_version(void) { return 100; }
+
+int ds_device_count(int *count)
+{
+    DS_REQUIRE(count != nullptr, "ds_device_count: null pointer");
+    *count = 0;
+    DS_HIP(hipGetDeviceCount(count));
+    return DS_OK;
+}
+
+int ds_device_name(int device, char *name, size_t capacity)
+{
+    DS_REQUIRE(name != nullptr && capacity > 0, "ds_device_name: bad buffer");
+    hipDeviceProp_t properties;
+    DS_HIP(hipGetDeviceProperties(&properties, device));
+    snprintf(name, capacity, "%s (%s, %d CUs)", properties.name, properties.gcnArchName,
+             properties.multiProcessorCount);
+    return DS_OK;
+}
+
+// ---- tiled index ---------------------------------------------------------------------------------------------------
+// Input: the V x N inverted index of match_maker.py:122-133 in CSR form.  Output (HBM): the truth rows are cut
+// into tiles of kTile rows; for every (tile, column) the posting sub-list is stored as uint16 tile-local rows,
+// padded to a multiple of four entries ("quad", one 8-byte load per lane) with kSentinel; tile_ptr[tile][column]
+// is the first quad of that sub-list.  The constant per-posting value of match_maker.py:130 is never stored.
+int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float *idf32, const float *sums32,
+                    int64_t V, int64_t N, int device, ds_index **out)
+{
+    DS_REQUIRE(out != nullptr, "ds_index_create: out is null");
+    *out = nullptr;
+    DS_REQUIRE(rowptr && idf32 && sums32, "ds_index_create: null input");
+    DS_REQUIRE(V > 0 && N > 0, "ds_index_create: V and N must be positive (V=%lld N=%lld)", (long long)V,
+               (long long)N);
+    DS_REQUIRE(N < (int64_t(1) << 31) - ds::kTile, "ds_index_create: N too large for int32 row indexes");
+    DS_REQUIRE(rowptr[0] == 0, "ds_index_create: rowptr[0] must be 0");
+    const int64_t nnz = rowptr[V];
+    DS_REQUIRE(nnz >= 0 && (nnz == 0 || truth_idx), "ds_index_create: bad nnz / truth_idx");
+    const int64_t n_tiles = (N + ds::kTile - 1) / ds::kTile;
+    const int64_t row_stride = V + 1;
+    DS_REQUIRE(n_tiles * row_stride < (int64_t(1) << 40), "ds_index_create: tile pointer table too large");
+
+    // pass 1: quads per (tile, column), validating the posting lists
+    std::vector<uint32_t> tile_ptr(static_cast<size_t>(n_tiles * row_stride), 0u);
+    for (int64_t g = 0; g < V; ++g) {
+        DS_REQUIRE(rowptr[g + 1] >= rowptr[g], "ds_index_create: rowptr not monotone at column %lld", (long long)g);
+        int64_t previous = -1;
+        for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
+            const int64_t t = truth_idx[p];
+            DS_REQUIRE(t > previous && t < N,
+                       "ds_index_create: posting list of column %lld is not strictly ascending within [0, N)",
+                       (long long)g);
+            previous = t;
+            ++tile_ptr[static_cast<size_t>((t >> ds::kTileLog2) * row_stride + g)];
+        }
+    }
+    uint64_t quads = 0;
+    for (int64_t b = 0; b < n_tiles; ++b) {
+        uint32_t *row = tile_ptr.data() + b * row_stride;
+        for (int64_t g = 0; g < V; ++g) {
+            const uint32_t count = row[g];
+            DS_REQUIRE(quads < 0xfffffff0ull, "ds_index_create: more than 2^32 posting quads");
+            row[g] = static_cast<uint32_t>(quads);
+            quads += (count + 3u) / 4u;
+        }
+        row[V] = static_cast<uint32_t>(quads);
+    }
+    // pass 2: fill
+    std::vector<uint16_t> postings(static_cast<size_t>(quads) * 4, static_cast<uint16_t>(ds::kSentinel));
+    {
+        std::vector<uint32_t> cursor(static_cast<size_t>(n_tiles), 0u);
+        for (int64_t g = 0; g < V; ++g) {
+            int64_t current_tile = -1;
+            uint64_t write = 0;
+            for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
+                const int64_t t = truth_idx[p];
+                const int64_t b = t >> ds::kTileLog2;
+                if (b != current_tile) {
+                    current_tile = b;
+                    write = static_cast<uint64_t>(tile_ptr[static_cast<size_t>(b * row_stride + g)]) * 4u;
+                }
+                postings[write++] = static_cast<uint16_t>(t & (ds::kTile - 1));
+            }
+        }
+    }
+    float sums_min = sums32[0];
+    for (int64_t t = 1; t < N; ++t) sums_min = std::min(sums_min, sums32[t]);
+
+    DS_HIP(hipSetDevice(device));
+    ds_index *index = new ds_index();
+    index->device = device;
+    index->n_truth = N;
+    index->n_columns = V;
+    index->nnz = nnz;
+    index->n_tiles = n_tiles;
+    index->n_quads = static_cast<int64_t>(quads);
+    index->sums_min = sums_min;
+    int status = index->tile_ptr.upload(tile_ptr.data(), tile_ptr.size());
+    if (status == DS_OK) status = index->postings.upload(postings.data(), postings.size());
+    if (status == DS_OK) status = index->idf32.upload(idf32, static_cast<size_t>(V));
+    if (status == DS_OK) status = index->sums32.upload(sums32, static_cast<size_t>(N));
+    if (status == DS_OK) status = index->slow_scratch.allocate(static_cast<size_t>(ds::kSlowSlots) * N);
+    if (status == DS_OK) status = index->control.allocate(16);
+    if (status == DS_OK && hipStreamCreate(&index->stream) != hipSuccess) {
+        ds::set_error("ds_index_create: hipStreamCreate failed");
+        status = DS_E_HIP;
+    }
+    if (status != DS_OK) {
+        delete index;
+        return status;
+    }
+    *out = index;
+    return DS_OK;
+}
+
+void ds_index_destroy(ds_index *index)
+{
+    if (!index) return;
+    (void)hipSetDevice(index->device);
+    if (index->stream) (void)hipStreamDestroy(index->stream);
+    delete index;
+}
+
+int ds_index_info(const ds_index *index, int64_t info[8])
+{
+    DS_REQUIRE(index && info, "ds_index_info: null argument");
+    info[0] = index->n_truth;
+    info[1] = index->n_columns;
+    info[2] = index->nnz;
+    info[3] = ds::kTile;
+    info[4] = index->n_tiles;
+    info[5] = static_cast<int64_t>(index->tile_ptr.bytes() + index->postings.bytes() + index->idf32.bytes() +
+                                   index->sums32.bytes() + index->slow_scratch.bytes());
+    info[6] = index->n_quads * 4;
+    info[7] = 0;
+    return DS_OK;
+}
+
+// ---- device memory / timers ----------------------------------------------------------------------------------------
+int ds_malloc(void **ptr, size_t bytes, int device)
+{
+    DS_REQUIRE(ptr != nullptr, "ds_malloc: null pointer");
+    DS_HIP(hipSetDevice(device));
+    DS_HIP(hipMalloc(ptr, bytes ? bytes : 1));
+    return DS_OK;
+}
+
+int ds_free(void *ptr, int device)
+{
+    DS_HIP(hipSetDevice(device));
+    DS_HIP(hipFree(ptr));
+    return DS_OK;
+}
+
+int ds_memcpy_h2d(void *dst, const void *src, size_t bytes, int device)
+{
+    DS_HIP(hipSetDevice(device));
+    if (bytes) DS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return DS_OK;
+}
+
+int ds_memcpy_d2h(void *dst, const void *src, size_t bytes, int device)
+{
+    DS_HIP(hipSetDevice(device));
+    if (bytes) DS_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return DS_OK;
+}
+
+int ds_memset(void *dst, int value, size_t bytes, int device)
+{
+    DS_HIP(hipSetDevice(device));
+    if (bytes) DS_HIP(hipMemset(dst, value, bytes));
+    return DS_OK;
+}
+
+int ds_stream_sync(void *stream, int device)
+{
+    DS_HIP(hipSetDevice(device));
+    DS_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return DS_OK;
+}
+
+}  // extern "C"
+
+struct ds_timer {
+    int device = 0;
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
+extern "C" {
+
+int ds_timer_create(int device, ds_timer **out)
+{
+    DS_REQUIRE(out != nullptr, "ds_timer_create: null pointer");
+    DS_HIP(hipSetDevice(device));
+    ds_timer *timer = new ds_timer();
+    timer->device = device;
+    if (hipEventCreate(&timer->start) != hipSuccess || hipEventCreate(&timer->stop) != hipSuccess) {
+        delete timer;
+        ds::set_error("ds_timer_create: hipEventCreate failed");
+        return DS_E_HIP;
+    }
+    *out = timer;
+    return DS_OK;
+}
+
+void ds_timer_destroy(ds_timer *timer)
+{
+    if (!timer) return;
+    if (timer->start) (void)hipEventDestroy(timer->start);
+    if (timer->stop) (void)hipEventDestroy(timer->stop);
+    delete timer;
+}
+
+int ds_timer_start(ds_timer *timer, void *stream)
+{
+    DS_REQUIRE(timer != nullptr, "ds_timer_start: null timer");
+    DS_HIP(hipEventRecord(timer->start, static_cast<hipStream_t>(stream)));
+    return DS_OK;
+}
+
+int ds_timer_stop(ds_timer *timer, void *stream)
+{
+    DS_REQUIRE(timer != nullptr, "ds_timer_stop: null timer");
+    DS_HIP(hipEventRecord(timer->stop, static_cast<hipStream_t>(stream)));
+    return DS_OK;
+}
+
+int ds_timer_elapsed_ms(ds_timer *timer, float *ms)
+{
+    DS_REQUIRE(timer != nullptr && ms != nullptr, "ds_timer_elapsed_ms: null argument");
+    DS_HIP(hipEventSynchronize(timer->stop));
+    DS_HIP(hipEventElapsedTime(ms, timer->start, timer->stop));
+    return DS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,216 @@
+"""MatchMaker: the reference's call surface (doppelspeller/match_maker.py:74-203) over the HIP Jaccard top-k kernels.
+
+`MatchMaker(data, truth_data, top_n)` takes the same two DataFrames as the reference (columns `n_grams` = set of
+character n-grams, `title_id`), builds the same vocabulary / IDF table / query rows / truth inverted index, uploads
+the index to HBM once (`TruthIndex`), and answers `get_closest_matches(row_number) -> list[title_id]`.  The
+reference computes one query per call inside a Python dict comprehension (predict.py:126-127); here the first call
+evaluates every row of `data` in one launch and later calls are cache reads.  `get_closest_matches_batch(rows)` is
+the explicit batched form.
+
+Host-side numerics follow the reference exactly (citations inline): IDF values are float64 `math.log`, stored as
+float32 in the matrices; `sums_matrix_truth[t]` is a sequential float32 sum in the iteration order of the title's
+n-gram `set`; `max_intersection_possible` is a sequential float64 sum in ascending column order.
+"""
+import ctypes
+import logging
+import math
+
+import numpy as np
+
+from . import _lib
+
+LOGGER = logging.getLogger(__name__)
+
+COLUMN_N_GRAMS = "n_grams"    # constants.py:6
+COLUMN_TITLE_ID = "title_id"  # constants.py:2
+ENCODING_FLOAT_TYPE = np.float32  # settings.py:71
+
+
+def sequential_sums(values, lengths, dtype):
+    """Row-wise sums of a ragged array with the rounding of a left-to-right loop (what Python's `sum` does).
+
+    values: flat array, row i = values[offsets[i]:offsets[i+1]]; returns one `dtype` per row.  Adding +0.0 to a
+    partial sum is exact, so padding the rows to a common length does not change any rounding.
+    """
+    lengths = np.asarray(lengths, dtype=np.int64)
+    offsets = np.concatenate(([0], np.cumsum(lengths)))
+    out = np.zeros(lengths.shape[0], dtype=dtype)
+    values = np.asarray(values, dtype=dtype)
+    longest = int(lengths.max()) if lengths.shape[0] else 0
+    for position in range(longest):
+        active = np.nonzero(lengths > position)[0]
+        out[active] = out[active] + values[offsets[active] + position]
+    return out
+
+
+class TruthIndex:
+    """The truth inverted index of match_maker.py:122-133 resident in HBM (ds_index_create)."""
+
+    def __init__(self, rowptr, truth_idx, idf32, sums32, device=0):
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        self.truth_idx = np.ascontiguousarray(truth_idx, dtype=np.int32)
+        self.idf32 = np.ascontiguousarray(idf32, dtype=np.float32)
+        self.sums32 = np.ascontiguousarray(sums32, dtype=np.float32)
+        self.device = device
+        self.n_columns = self.rowptr.shape[0] - 1
+        self.n_truth = self.sums32.shape[0]
+        if self.idf32.shape[0] != self.n_columns:
+            raise ValueError("idf32 must have one entry per column")
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.lib().ds_index_create(
+            _lib.pointer(self.rowptr), _lib.pointer(self.truth_idx), _lib.pointer(self.idf32),
+            _lib.pointer(self.sums32), self.n_columns, self.n_truth, device, ctypes.byref(self.handle)),
+            "ds_index_create")
+
+    def info(self):
+        raw = (ctypes.c_int64 * 8)()
+        _lib.check(_lib.lib().ds_index_info(self.handle, raw), "ds_index_info")
+        keys = ("n_truth", "n_columns", "nnz", "tile_rows", "tiles", "device_bytes", "padded_postings")
+        return dict(zip(keys, list(raw)[:7]))
+
+    def top_k(self, q_rowptr, q_cols, q_maxint, k):
+        """fast_jaccard + fast_arg_top_k for a batch: int32[Q, k] truth rows, descending row index per query."""
+        q_rowptr = np.ascontiguousarray(q_rowptr, dtype=np.int64)
+        q_cols = np.ascontiguousarray(q_cols, dtype=np.int32)
+        q_maxint = np.ascontiguousarray(q_maxint, dtype=np.float64)
+        n_queries = q_rowptr.shape[0] - 1
+        if q_maxint.shape[0] != n_queries:
+            raise ValueError("q_maxint must have one entry per query")
+        out = np.empty((n_queries, k), dtype=np.int32)
+        _lib.check(_lib.lib().ds_jaccard_topk(self.handle, _lib.pointer(q_rowptr), _lib.pointer(q_cols),
+                                              _lib.pointer(q_maxint), n_queries, k, _lib.pointer(out)),
+                   "ds_jaccard_topk")
+        return out
+
+    def top_k_device(self, d_q_rowptr, d_q_cols, d_q_maxint, n_queries, k, d_out_rows, stream=None):
+        """Enqueue on `stream` with every operand already in HBM (raw device pointers as ints / c_void_p)."""
+        as_ptr = lambda x: x if isinstance(x, ctypes.c_void_p) else ctypes.c_void_p(int(x))
+        _lib.check(_lib.lib().ds_jaccard_topk_device(
+            self.handle, as_ptr(d_q_rowptr), as_ptr(d_q_cols), as_ptr(d_q_maxint), n_queries, k, as_ptr(d_out_rows),
+            ctypes.c_void_p(stream or 0)), "ds_jaccard_topk_device")
+
+    def sync(self, stream=None):
+        stats = (ctypes.c_int64 * 4)()
+        _lib.check(_lib.lib().ds_jaccard_sync(self.handle, ctypes.c_void_p(stream or 0), stats), "ds_jaccard_sync")
+        return {"dense_queries": stats[0], "error_queries": stats[1], "exact_candidates": stats[2],
+                "selections": stats[3]}
+
+    def close(self):
+        if self.handle:
+            _lib.lib().ds_index_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MatchMaker:
+    """
+    The class responsible for getting the closest (based on Jaccard distance) titles, given a collection of titles.
+
+    :param data: (dataframe) The collection of titles for which to find the closest titles
+    :param truth_data: (dataframe) The "truth" database
+    :param top_n: (int) Top n values to fetch
+    :param device: HIP device ordinal
+    :param vocabulary: optional explicit column order (list of n-grams); the reference uses the iteration order
+        of a Python set (match_maker.py:145-147), which depends on PYTHONHASHSEED -- tests inject the captured one.
+
+    * Main public method: get_closest_matches(...)
+    """
+
+    def __init__(self, data, truth_data, top_n, device=0, vocabulary=None):
+        self.data = data
+        self.truth_data = truth_data
+        self.top_n = top_n
+
+        LOGGER.info(f'[{self.__class__.__name__}] Loading pre-requisite data!')
+
+        self.n_grams_counter = self._count(self.data[COLUMN_N_GRAMS])               # match_maker.py:91
+        self.n_grams_counter_truth = self._count(self.truth_data[COLUMN_N_GRAMS])   # :92
+        self.number_of_truth_titles = len(self.truth_data)                           # :93
+        self.idf_s_mapping = {key: math.log(self.number_of_truth_titles / count)     # :135-142 (float64)
+                              for key, count in self.n_grams_counter_truth.items()}
+        self.max_idf_value = max(self.idf_s_mapping.values())                        # :95
+        if vocabulary is None:                                                       # :144-147
+            vocabulary = set(list(self.n_grams_counter.keys()) + list(self.n_grams_counter_truth.keys()))
+        self.n_grams_decoding = {index: n_gram for index, n_gram in enumerate(vocabulary)}
+        self.n_grams_encoding = {v: k for k, v in self.n_grams_decoding.items()}     # :97
+        n_columns = len(self.n_grams_decoding)
+        # idf per column, float64 (_get_idf_given_index, :180-181) and its float32 image (the matrix dtype, :152)
+        self._idf64 = np.array([self.idf_s_mapping.get(self.n_grams_decoding[g], self.max_idf_value)
+                                for g in range(n_columns)], dtype=np.float64)
+        idf32 = self._idf64.astype(ENCODING_FLOAT_TYPE)
+
+        self._q_rowptr, self._q_cols, self._q_maxint = self._construct_data_rows(idf32)   # :99, :106, :197
+        del self.data                                                                       # :100
+
+        rowptr, truth_idx, self.sums_matrix_truth = self._construct_truth_index(idf32, n_columns)  # :102-107
+        self.truth_data = self.truth_data.loc[:, [COLUMN_TITLE_ID]]                         # :104
+        self.index = TruthIndex(rowptr, truth_idx, idf32, self.sums_matrix_truth, device)
+        self._rows = None
+
+        LOGGER.info(f'[{self.__class__.__name__}] Loaded pre-requisite data!')
+
+    @staticmethod
+    def _count(column):  # common.py:145-147 get_n_grams_counter
+        counter = {}
+        for n_grams in column:
+            for n_gram in set(n_grams):
+                counter[n_gram] = counter.get(n_gram, 0) + 1
+        return counter
+
+    def _flatten(self, column):
+        """(row lengths, flat column ids in each set's iteration order) -- the order `_get_encoding_values` sees."""
+        encoding = self.n_grams_encoding
+        lengths = np.fromiter((len(n_grams) for n_grams in column), dtype=np.int64, count=len(column))
+        flat = np.fromiter((encoding[n_gram] for n_grams in column for n_gram in n_grams), dtype=np.int64,
+                           count=int(lengths.sum()))
+        return lengths, flat
+
+    def _construct_data_rows(self, idf32):
+        """matrix_non_zero_columns (:111-120) as CSR + max_intersection_possible (:197) per row."""
+        lengths, flat = self._flatten(self.data[COLUMN_N_GRAMS])
+        rows = np.repeat(np.arange(lengths.shape[0], dtype=np.int64), lengths)
+        keep = idf32[flat] != 0                       # lil_matrix(...).nonzero() drops explicit zeros (:118)
+        rows, flat = rows[keep], flat[keep]
+        order = np.lexsort((flat, rows))              # .nonzero()[1] of a lil row: ascending column ids
+        rows, flat = rows[order], flat[order]
+        counts = np.bincount(rows, minlength=lengths.shape[0]).astype(np.int64)
+        rowptr = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
+        maxint = sequential_sums(self._idf64[flat], counts, np.float64)   # Python sum of float64, column order
+        return rowptr, flat.astype(np.int32), maxint
+
+    def _construct_truth_index(self, idf32, n_columns):
+        """matrix_truth_non_zero_columns_and_values (:122-133) as CSR + sums_matrix_truth (:102, :174)."""
+        lengths, flat = self._flatten(self.truth_data[COLUMN_N_GRAMS])
+        sums = sequential_sums(idf32[flat], lengths, ENCODING_FLOAT_TYPE)  # sum(uniqueness_values), set order
+        rows = np.repeat(np.arange(lengths.shape[0], dtype=np.int64), lengths)
+        keep = idf32[flat] != 0
+        rows, flat = rows[keep], flat[keep]
+        order = np.argsort(flat, kind="stable")       # rows stay ascending within a column
+        truth_idx = rows[order].astype(np.int32)
+        rowptr = np.concatenate(([0], np.cumsum(np.bincount(flat, minlength=n_columns)))).astype(np.int64)
+        return rowptr, truth_idx, sums
+
+    def get_closest_matches_batch(self, row_numbers=None):
+        """Truth ROW indexes int32[len(rows), top_n] (descending row index) for the given rows of `data`."""
+        if self._rows is None:
+            self._rows = self.index.top_k(self._q_rowptr, self._q_cols, self._q_maxint, self.top_n)
+        if row_numbers is None:
+            return self._rows
+        return self._rows[np.asarray(row_numbers, dtype=np.int64)]
+
+    def _get_top_n_matches(self, top_matches):
+        """For the selected truth rows, gets the title_id's from self.truth_data (:183-190)."""
+        if top_matches.shape[0] != self.top_n:
+            raise Exception('top_matches.shape[0] != self.top_n')
+        return self.truth_data.loc[top_matches, COLUMN_TITLE_ID].tolist()
+
+    def get_closest_matches(self, row_number):
+        """
+        Given the "row_number" of self.data, gets the closest (self.top_n) titles in self.truth_data
+        """
+        return self._get_top_n_matches(self.get_closest_matches_batch()[row_number])

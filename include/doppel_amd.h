@@ -1,0 +1,119 @@
+/*
+ * doppel_amd.h -- C ABI of libdoppel_amd.so, the MI355X (gfx950) implementation of doppel-speller's
+ * candidate-generation-and-scoring hot path.
+ *
+ * Every entry point replaces one piece of the reference's numba-jitted path; the reference interface it stands in
+ * for is cited as `file:line` relative to the reference repository (mhaseebtariq/doppel-speller).  The reference is
+ * Python, so the "FFI" a maintainer would add is a ctypes binding: see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all buffers are caller-owned and contiguous;
+ *   - functions return 0 on success and a negative DS_E_* code on failure; ds_last_error() returns a
+ *     thread-local human-readable message for the last failure; no exception crosses the boundary;
+ *   - "host" entry points take host pointers and copy H<->D themselves (synchronous); "_device" entry points take
+ *     device pointers plus a hipStream_t (as void*) and only enqueue work on that stream;
+ *   - a handle is bound to one device, owns its device memory, and is NOT thread-safe (one caller at a time,
+ *     like the reference's single Python thread);
+ *   - there is no CPU fallback: without a usable GPU every compute entry point fails with DS_E_HIP.
+ */
+#ifndef DOPPEL_AMD_H
+#define DOPPEL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DS_FEATURES_COUNT 66 /* feature_engineering.py:67  FEATURES_COUNT = 6 + 4 * NUMBER_OF_WORDS_FEATURES */
+#define DS_WORDS 15          /* settings.py:65            NUMBER_OF_WORDS_FEATURES */
+#define DS_MAX_CHARS 255     /* settings.py:68            MAX_CHARACTERS_ALLOWED_IN_THE_TITLE */
+
+#define DS_OK 0
+#define DS_E_ARG (-1)      /* invalid argument (null pointer, bad size, unsorted posting list ...) */
+#define DS_E_HIP (-2)      /* HIP runtime failure (no device, out of memory, launch failure) */
+#define DS_E_TOP_N (-3)    /* fewer than k rows qualify: the reference raises 'top_matches.shape[0] != self.top_n'
+                              (match_maker.py:188-189) */
+#define DS_E_INTERNAL (-4)
+
+typedef struct ds_index ds_index;   /* truth inverted index resident in HBM (MatchMaker.__init__ product) */
+typedef struct ds_titles ds_titles; /* table of encoded titles resident in HBM */
+typedef struct ds_timer ds_timer;   /* pair of HIP events */
+
+/* ---- library ---------------------------------------------------------------------------------------------------- */
+const char *ds_last_error(void);
+int ds_version(void);
+int ds_device_count(int *count);
+int ds_device_name(int device, char *name, size_t capacity);
+
+/* ---- truth index:  MatchMaker.__init__ product (match_maker.py:99-107) ------------------------------------------ */
+/* rowptr[V+1], truth_idx[nnz]: the V x N inverted index of match_maker.py:122-133 in CSR form (row g = n-gram
+ * column g, entries = ascending truth row indexes).  idf32[V] = the constant per-posting value of :130.
+ * sums32[N] = sums_matrix_truth of :102,174.  The per-posting value array of the reference is not stored. */
+int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float *idf32, const float *sums32,
+                    int64_t V, int64_t N, int device, ds_index **out);
+void ds_index_destroy(ds_index *index);
+/* info[0]=N info[1]=V info[2]=nnz info[3]=tile size info[4]=tiles info[5]=device bytes info[6]=padded postings */
+int ds_index_info(const ds_index *index, int64_t info[8]);
+
+/* ---- Jaccard top-k:  fast_jaccard + fast_arg_top_k (match_maker.py:16-71) behind get_closest_matches (:192-203) - */
+/* For each query q: columns q_cols[q_rowptr[q] .. q_rowptr[q+1]) in ACCUMULATION ORDER (the order of
+ * matrix_non_zero_columns[row], :118), q_maxint[q] = max_intersection_possible (:197, float64).
+ * out_rows[q*k .. q*k+k) = truth ROW indexes in descending row-index order, exactly
+ * `(array >= threshold).nonzero()[0][::-1][:k]` of :71 (the title_id mapping of :190 is the caller's). */
+int ds_jaccard_topk(ds_index *index, const int64_t *q_rowptr, const int32_t *q_cols, const double *q_maxint,
+                    int64_t Q, int32_t k, int32_t *out_rows);
+/* Same with every array already in HBM; enqueues on `stream` and returns without synchronising.
+ * q_nnz = q_rowptr[Q].  Errors detected on the device (DS_E_TOP_N ...) are reported by ds_jaccard_sync(). */
+int ds_jaccard_topk_device(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q_cols,
+                           const double *d_q_maxint, int64_t Q, int32_t k, int32_t *d_out_rows, void *stream);
+/* Waits for `stream`, returns the status of the last ds_jaccard_topk_device on this index;
+ * stats[0]=queries answered by the exact dense kernel, stats[1]=queries in error, stats[2]=candidates evaluated
+ * exactly (total), stats[3]=threshold selections run (total). */
+int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[4]);
+
+/* ---- Levenshtein / features:  fast_levenshtein_ratio + construct_features (feature_engineering.py:25-169) ------- */
+/* The 9-argument gufunc of feature_engineering.py:69-80 without the `dummy` argument: rows of q_enc / t_enc are
+ * `stride` bytes apart (255 in predict.py:199-202), out = float32[n*66] written in place.  Host pointers. */
+int ds_construct_features(const uint8_t *q_len, const uint8_t *t_len, const uint8_t *q_enc, const uint8_t *t_enc,
+                          const uint32_t *t_word_counts, uint8_t space_code, uint32_t n_truth, int64_t n,
+                          int64_t stride, int device, float *out);
+
+/* Encoded titles uploaded once (FeatureEngineering.encode_title rows, feature_engineering.py:298-307, and for a
+ * truth table get_truth_words_counts rows, :309-319; word_counts may be NULL for a query table). */
+int ds_titles_create(const uint8_t *enc, int64_t stride, const uint8_t *len, const uint32_t *word_counts, int64_t n,
+                     int device, ds_titles **out);
+void ds_titles_destroy(ds_titles *titles);
+/* Pairs given as (query row, truth row) indexes into two tables: out[i] = construct_features(q[pair_q[i]],
+ * t[pair_t[i]]).  Host pointers for pair_q / pair_t / out. */
+int ds_construct_features_indexed(ds_titles *queries, ds_titles *truth, const int32_t *pair_q, const int32_t *pair_t,
+                                  uint8_t space_code, uint32_t n_truth, int64_t n, float *out);
+/* Device-resident variant for the fused pipeline: d_pair_t = the top-k rows written by ds_jaccard_topk_device,
+ * pair i belongs to query row q_first + i / k when d_pair_q is NULL.  d_out = float32[n*66] in HBM. */
+int ds_construct_features_indexed_device(ds_titles *queries, ds_titles *truth, const int32_t *d_pair_q,
+                                         const int32_t *d_pair_t, int64_t q_first, int32_t k, uint8_t space_code,
+                                         uint32_t n_truth, int64_t n, float *d_out, void *stream);
+/* fast_levenshtein_ratio (feature_engineering.py:25-63) for n independent pairs of code strings:
+ * a = a_chars[a_off[i] .. a_off[i+1]), b likewise; out[i] = ratio (uint8).  Host pointers.
+ * method 0 = bit-parallel LCS kernel (exact uint8-wrap DP where lengths require it), 1 = anti-diagonal DP kernel. */
+int ds_levenshtein_ratio_batch(const uint8_t *a_chars, const int64_t *a_off, const uint8_t *b_chars,
+                               const int64_t *b_off, int64_t n, int method, int device, uint8_t *out);
+
+/* ---- device memory / stream / timing plumbing (so tests and bench.py can keep inputs resident in HBM) ----------- */
+int ds_malloc(void **ptr, size_t bytes, int device);
+int ds_free(void *ptr, int device);
+int ds_memcpy_h2d(void *dst, const void *src, size_t bytes, int device);
+int ds_memcpy_d2h(void *dst, const void *src, size_t bytes, int device);
+int ds_memset(void *dst, int value, size_t bytes, int device);
+int ds_stream_sync(void *stream, int device);
+int ds_timer_create(int device, ds_timer **out);
+void ds_timer_destroy(ds_timer *timer);
+int ds_timer_start(ds_timer *timer, void *stream);
+int ds_timer_stop(ds_timer *timer, void *stream);
+int ds_timer_elapsed_ms(ds_timer *timer, float *ms); /* synchronises on the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOPPEL_AMD_H */

@@ -226,7 +226,9 @@ def main():
             fixture.update(rowptr=rowptr, truth_idx=truth_idx, idf32=idf32,
                            sums32=mm.sums_matrix_truth.astype(np.float32), q_rowptr=q_rowptr, q_cols=q_cols,
                            q_maxint=q_maxint, title_id=np.asarray(truth[c.COLUMN_TITLE_ID], dtype=np.int64),
-                           vocab=np.array(sorted(mm.n_grams_encoding, key=mm.n_grams_encoding.get)))
+                           vocab=np.array(sorted(mm.n_grams_encoding, key=mm.n_grams_encoding.get)),
+                           truth_titles=np.array(list(truth[c.COLUMN_TRANSFORMED_TITLE])),
+                           query_titles=np.array(list(query[c.COLUMN_TRANSFORMED_TITLE])))
             # full float64 jaccard arrays for a few queries (pins fast_jaccard on its own)
             jac_rows = [0, 1, 2, 3, 50, 199]
             jac = np.stack([match_maker.fast_jaccard(

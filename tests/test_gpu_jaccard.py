@@ -1,0 +1,162 @@
+"""GPU parity of the Jaccard top-k path (through the C ABI) against the oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_problem(rng, n_truth, n_columns, n_queries, mean_cols=12, heavy=6, duplicates=0):
+    """Random inverted index with a few heavy columns, and queries that reuse truth rows' columns."""
+    rows, cols = [], []
+    per_row = np.clip(rng.poisson(mean_cols, n_truth), 1, 60)
+    for t in range(n_truth):
+        c = set(rng.randint(heavy, n_columns, per_row[t]).tolist())
+        for h in range(heavy):
+            if rng.rand() < 0.3:
+                c.add(h)
+        rows.append(np.full(len(c), t))
+        cols.append(np.array(sorted(c)))
+    if duplicates:
+        for t in range(1, duplicates):
+            cols[t] = cols[0]
+            rows[t] = np.full(len(cols[0]), t)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    order = np.argsort(cols, kind="stable")
+    truth_idx = rows[order].astype(np.int32)
+    df = np.bincount(cols, minlength=n_columns)
+    rowptr = np.concatenate(([0], np.cumsum(df))).astype(np.int64)
+    idf64 = np.log(n_truth / np.maximum(df, 1))
+    idf64[df == 0] = idf64.max()
+    idf32 = idf64.astype(np.float32)
+    sums32 = np.zeros(n_truth, dtype=np.float32)
+    by_row = np.argsort(rows, kind="stable")
+    for r, c in zip(rows[by_row], cols[by_row]):
+        sums32[r] = sums32[r] + idf32[c]
+    q_cols, q_rowptr, q_maxint = [], [0], []
+    for q in range(n_queries):
+        base = cols[rows == rng.randint(n_truth)] if rng.rand() < 0.7 else np.array([], dtype=np.int64)
+        extra = rng.randint(0, n_columns, rng.randint(1, 10))
+        c = np.unique(np.concatenate((base[rng.rand(base.shape[0]) < 0.8], extra))).astype(np.int64)
+        c = c[idf32[c] != 0]
+        q_cols.append(c)
+        q_rowptr.append(q_rowptr[-1] + c.shape[0])
+        total = 0.0
+        for value in idf64[c]:
+            total = total + float(value)
+        q_maxint.append(total)
+    return dict(rowptr=rowptr, truth_idx=truth_idx, idf32=idf32, sums32=sums32,
+                q_rowptr=np.array(q_rowptr, dtype=np.int64), q_cols=np.concatenate(q_cols).astype(np.int32),
+                q_maxint=np.array(q_maxint, dtype=np.float64))
+
+
+def _check(oracle, problem, k):
+    import doppel_speller_amd as ds
+    index = ds.TruthIndex(problem["rowptr"], problem["truth_idx"], problem["idf32"], problem["sums32"])
+    got = index.top_k(problem["q_rowptr"], problem["q_cols"], problem["q_maxint"], k)
+    expected = oracle.jaccard_topk(problem["rowptr"], problem["truth_idx"], problem["idf32"], problem["sums32"],
+                                   problem["q_rowptr"], problem["q_cols"], problem["q_maxint"], k)
+    bad = np.nonzero((got != expected).any(axis=1))[0]
+    assert bad.shape[0] == 0, (bad[:10], got[bad[:2]], expected[bad[:2]])
+    return index
+
+
+def test_golden_fixture(oracle, golden_match_maker):
+    import doppel_speller_amd as ds
+    g = golden_match_maker
+    index = ds.TruthIndex(g["rowptr"], g["truth_idx"], g["idf32"], g["sums32"])
+    for k in (10, 100):
+        got = index.top_k(g["q_rowptr"], g["q_cols"], g["q_maxint"], k)
+        ok = g[f"margin_ok_k{k}"]
+        assert np.array_equal(got[ok], g[f"rows_k{k}"][ok])          # captured from the reference
+        expected = oracle.jaccard_topk(g["rowptr"], g["truth_idx"], g["idf32"], g["sums32"], g["q_rowptr"],
+                                       g["q_cols"], g["q_maxint"], k)
+        assert np.array_equal(got, expected)                          # every vector, specification typing
+        assert np.array_equal(g["title_id"][got[ok]], g[f"ids_k{k}"][ok])
+
+
+@pytest.mark.parametrize("n_truth,k", [(1000, 10), (40000, 10), (70001, 50), (98304, 100)])
+def test_random_against_oracle(oracle, n_truth, k):
+    rng = np.random.RandomState(n_truth + k)
+    problem = _random_problem(rng, n_truth, 3000, 96)
+    index = _check(oracle, problem, k)
+    assert index.sync()["error_queries"] == 0
+
+
+def test_ties_and_duplicates(oracle):
+    rng = np.random.RandomState(5)
+    problem = _random_problem(rng, 50000, 2000, 40, duplicates=6000)  # 6000 identical truth rows: massive ties
+    # make several queries equal to the duplicated row so the ties sit at the top
+    first = problem["truth_idx"] == 0
+    cols0 = np.repeat(np.arange(problem["rowptr"].shape[0] - 1), np.diff(problem["rowptr"]))[first]
+    q_cols = [problem["q_cols"][problem["q_rowptr"][q]:problem["q_rowptr"][q + 1]] for q in range(40)]
+    for q in range(0, 40, 4):
+        q_cols[q] = cols0.astype(np.int32)
+    problem["q_rowptr"] = np.concatenate(([0], np.cumsum([len(c) for c in q_cols]))).astype(np.int64)
+    problem["q_cols"] = np.concatenate(q_cols).astype(np.int32)
+    idf64 = problem["idf32"].astype(np.float64)
+    problem["q_maxint"] = np.array([float(np.sum(idf64[c])) for c in q_cols])
+    index = _check(oracle, problem, 10)
+    stats = index.sync()
+    assert stats["dense_queries"] >= 1  # the tie-heavy queries must have used the exact dense kernel
+
+
+def test_edge_cases(oracle):
+    rng = np.random.RandomState(11)
+    problem = _random_problem(rng, 5000, 800, 8)
+    n_columns = problem["rowptr"].shape[0] - 1
+    unused = np.nonzero(np.diff(problem["rowptr"]) == 0)[0]
+    q_cols = [
+        np.array([], dtype=np.int32),                                  # empty query: fewer than k positives
+        unused[:3].astype(np.int32) if unused.shape[0] >= 3 else np.array([], dtype=np.int32),  # unseen n-grams
+        np.arange(0, 300, dtype=np.int32) % n_columns,                 # > 256 columns (not unique on purpose? no)
+        np.array([5], dtype=np.int32),
+    ]
+    q_cols[2] = np.unique(q_cols[2]).astype(np.int32)
+    wide = np.unique(rng.randint(0, n_columns, 400)).astype(np.int32)  # more than 256 distinct columns
+    q_cols.append(wide)
+    idf64 = problem["idf32"].astype(np.float64)
+    problem["q_rowptr"] = np.concatenate(([0], np.cumsum([len(c) for c in q_cols]))).astype(np.int64)
+    problem["q_cols"] = np.concatenate(q_cols).astype(np.int32)
+    maxint = []
+    for c in q_cols:
+        total = 0.0
+        for value in idf64[c]:
+            total = total + float(value)
+        maxint.append(total)
+    maxint[0] = 1.0  # an empty query with a positive maxint (never produced by MatchMaker, still well defined)
+    problem["q_maxint"] = np.array(maxint)
+    for k in (1, 10, 100):
+        _check(oracle, problem, k)
+
+
+def test_k_larger_than_truth_raises(oracle):
+    import doppel_speller_amd as ds
+    rng = np.random.RandomState(3)
+    problem = _random_problem(rng, 50, 100, 2)
+    index = ds.TruthIndex(problem["rowptr"], problem["truth_idx"], problem["idf32"], problem["sums32"])
+    with pytest.raises(Exception, match="top_matches.shape"):
+        index.top_k(problem["q_rowptr"], problem["q_cols"], problem["q_maxint"], 51)
+    assert index.top_k(problem["q_rowptr"], problem["q_cols"], problem["q_maxint"], 50).shape == (2, 50)
+
+
+def test_match_maker_drop_in(golden_match_maker):
+    """The reference's call surface on DataFrames, with the captured vocabulary order injected."""
+    import pandas as pd
+    import doppel_speller_amd as ds
+    g = golden_match_maker
+    n_grams = lambda title: set(title[i:i + 3] for i in range(len(title)) if len(title[i:i + 3]) == 3)
+    truth = pd.DataFrame({"title_id": g["title_id"], "n_grams": [n_grams(str(t)) for t in g["truth_titles"]]})
+    data = pd.DataFrame({"n_grams": [n_grams(str(t)) for t in g["query_titles"]]})
+    mm = ds.MatchMaker(data, truth, 10, vocabulary=[str(v) for v in g["vocab"]])
+    assert mm.top_n == 10 and mm.number_of_truth_titles == 5000 and not hasattr(mm, "data")
+    assert list(mm.truth_data.columns) == ["title_id"]
+    assert np.array_equal(mm.index.idf32, g["idf32"]) and np.array_equal(mm.index.rowptr, g["rowptr"])
+    assert np.array_equal(mm.index.truth_idx, g["truth_idx"])
+    assert np.array_equal(mm._q_cols, g["q_cols"]) and np.array_equal(mm._q_maxint, g["q_maxint"])
+    assert np.allclose(mm.sums_matrix_truth, g["sums32"], rtol=1e-6)  # set iteration order may differ (H6)
+    agree = 0
+    for q in range(200):
+        ids = mm.get_closest_matches(q)
+        assert isinstance(ids, list) and len(ids) == 10
+        agree += ids == g["ids_k10"][q].tolist()
+    assert agree >= 198  # identical unless a set-order rounding difference in sums flips a near-tie

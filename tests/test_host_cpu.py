@@ -1,0 +1,142 @@
+"""CPU-only checks: host-side logic of the package, the C ABI surface, the synthetic generator."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def library():
+    import doppel_speller_amd as ds
+    return ctypes.CDLL(ds.build_library())
+
+
+def test_library_exports_every_declared_symbol(library):
+    header = open(os.path.join(ROOT, "include", "doppel_amd.h")).read()
+    declared = set(re.findall(r"\b(ds_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(library, name), name
+    from doppel_speller_amd import _lib
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_argument_errors_without_gpu(library):
+    library.ds_last_error.restype = ctypes.c_char_p
+    out = ctypes.c_void_p()
+    assert library.ds_index_create(None, None, None, None, ctypes.c_int64(0), ctypes.c_int64(0), 0,
+                                   ctypes.byref(out)) == -1
+    assert b"null" in library.ds_last_error() or b"positive" in library.ds_last_error()
+    rowptr = np.array([0, 2], dtype=np.int64)
+    idx = np.array([3, 1], dtype=np.int32)  # not ascending
+    one = np.ones(4, dtype=np.float32)
+    status = library.ds_index_create(rowptr.ctypes.data_as(ctypes.c_void_p), idx.ctypes.data_as(ctypes.c_void_p),
+                                     one.ctypes.data_as(ctypes.c_void_p), one.ctypes.data_as(ctypes.c_void_p),
+                                     ctypes.c_int64(1), ctypes.c_int64(4), 0, ctypes.byref(out))
+    assert status == -1 and b"ascending" in library.ds_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    package = os.path.join(ROOT, "doppel-speller_amd")
+    for directory, _, files in os.walk(package):
+        for name in files:
+            if name.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(directory, name)).read()
+                assert "oracle" not in text.replace("# oracle", ""), os.path.join(directory, name)
+
+
+def test_encoders_known_answers(golden_kat):
+    import doppel_speller_amd as ds
+    assert ds.ALLOWED_CHARACTERS == golden_kat["alphabet"] and ds.SPACE_CODE == golden_kat["space_code"]
+    for title, expected in golden_kat["encode_title"].items():
+        got = ds.encode_title(title)
+        assert got.dtype == np.uint8 and got.shape == (255,)
+        assert got[:len(expected)].tolist() == expected and not got[len(title):].any()
+    enc, lengths = ds.encode_titles(list(golden_kat["encode_title"]))
+    for row, title in enumerate(golden_kat["encode_title"]):
+        assert np.array_equal(enc[row], ds.encode_title(title)) and lengths[row] == len(title)
+    counter = {"great": 4, "expectations": 2}
+    assert ds.get_truth_words_counts("great expectations", counter).tolist() == [4, 2] + [0] * 13
+
+
+def test_sequential_sums_are_left_to_right():
+    from doppel_speller_amd.match_maker import sequential_sums
+    rng = np.random.RandomState(0)
+    lengths = rng.randint(0, 40, 200)
+    values = (rng.rand(lengths.sum()) * 10).astype(np.float32)
+    got = sequential_sums(values, lengths, np.float32)
+    at = 0
+    for i, n in enumerate(lengths):
+        total = 0
+        for v in values[at:at + n]:
+            total = total + v
+        at += n
+        assert np.float32(total) == got[i]
+
+
+def test_match_maker_host_side_matches_captured_structures(golden_match_maker, monkeypatch):
+    """MatchMaker's host construction against the structures captured from the reference (no GPU needed)."""
+    import pandas as pd
+    from doppel_speller_amd import match_maker
+    g = golden_match_maker
+
+    class FakeIndex:
+        def __init__(self, rowptr, truth_idx, idf32, sums32, device=0):
+            self.rowptr, self.truth_idx, self.idf32, self.sums32 = rowptr, truth_idx, idf32, sums32
+
+    monkeypatch.setattr(match_maker, "TruthIndex", FakeIndex)
+    n_grams = lambda title: set(title[i:i + 3] for i in range(len(title)) if len(title[i:i + 3]) == 3)
+    truth = pd.DataFrame({"title_id": g["title_id"], "n_grams": [n_grams(str(t)) for t in g["truth_titles"]]})
+    data = pd.DataFrame({"n_grams": [n_grams(str(t)) for t in g["query_titles"]]})
+    mm = match_maker.MatchMaker(data, truth, 10, vocabulary=[str(v) for v in g["vocab"]])
+    assert np.array_equal(mm.index.rowptr, g["rowptr"]) and np.array_equal(mm.index.truth_idx, g["truth_idx"])
+    assert np.array_equal(mm.index.idf32, g["idf32"])
+    assert np.array_equal(mm._q_rowptr, g["q_rowptr"]) and np.array_equal(mm._q_cols, g["q_cols"])
+    assert np.array_equal(mm._q_maxint, g["q_maxint"])
+    # the float32 rounding of sums_matrix_truth follows the iteration order of each title's n-gram set, which depends
+    # on PYTHONHASHSEED: close here, bit-exact in the pinned-seed test below
+    assert np.allclose(mm.sums_matrix_truth, g["sums32"], rtol=4e-6)
+
+
+def test_sums_matrix_truth_bit_exact_under_the_captured_hash_seed():
+    """Same check in a child interpreter with PYTHONHASHSEED=0 (the seed the goldens were captured with)."""
+    import subprocess
+    import sys
+    script = """
+import numpy as np, pandas as pd, sys
+sys.path.insert(0, %r)
+from doppel_speller_amd import match_maker
+g = np.load(%r)
+class FakeIndex:
+    def __init__(self, *a, **k): pass
+match_maker.TruthIndex = FakeIndex
+n_grams = lambda title: set([title[i:i + 3] for i in range(len(title)) if len(title[i:i + 3]) == 3])
+truth = pd.DataFrame({"title_id": g["title_id"], "n_grams": [n_grams(str(t)) for t in g["truth_titles"]]})
+data = pd.DataFrame({"n_grams": [n_grams(str(t)) for t in g["query_titles"]]})
+mm = match_maker.MatchMaker(data, truth, 10, vocabulary=[str(v) for v in g["vocab"]])
+assert np.array_equal(mm.sums_matrix_truth.view(np.uint32), g["sums32"].view(np.uint32))
+print("exact")
+""" % (ROOT, os.path.join(ROOT, "tests", "golden", "match_maker_5000x200.npz"))
+    env = dict(os.environ, PYTHONHASHSEED="0")
+    result = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert result.returncode == 0 and "exact" in result.stdout, result.stderr[-2000:]
+
+
+def test_synthetic_workload_acceptance(oracle):
+    from doppel_speller_amd import synth
+    w = synth.make_workload(30000, 500, seed=synth.DEFAULT_SEED)
+    again = synth.make_workload(30000, 500, seed=synth.DEFAULT_SEED)
+    assert np.array_equal(w.truth_idx, again.truth_idx) and np.array_equal(w.q_cols, again.q_cols)
+    stats = synth.workload_statistics(w)
+    assert 19 <= stats["tri_grams_per_truth_title"] <= 23
+    assert 0.75 <= stats["postings_touched_per_query_over_n"] <= 1.05
+    assert stats["columns"] <= 37 ** 3 + 38 ** 2
+    assert (np.diff(w.q_cols.astype(np.int64))[np.diff(np.repeat(np.arange(500), np.diff(w.q_rowptr))) == 0] > 0).all()
+    rows = oracle.jaccard_topk(w.rowptr, w.truth_idx, w.idf32, w.sums32, w.q_rowptr, w.q_cols, w.q_maxint, 10)
+    derived = w.actual_row >= 0
+    recall = np.mean([w.actual_row[q] in rows[q] for q in np.nonzero(derived)[0]])
+    assert 0.55 <= derived.mean() <= 0.65 and recall > 0.8
