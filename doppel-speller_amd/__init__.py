@@ -16,3 +16,4 @@ from .feature_engineering import (  # noqa: F401
     FEATURES_COUNT, TitleTable, construct_features, construct_features_indexed, encode_title, encode_titles,
     get_truth_words_counts, levenshtein_ratio_batch, ALLOWED_CHARACTERS, SPACE_CODE)
 from .match_maker import MatchMaker, TruthIndex  # noqa: F401
+from .pipeline import CandidatePipeline  # noqa: F401

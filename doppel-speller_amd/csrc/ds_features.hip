@@ -276,9 +276,19 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(
             maximum = (other != other) ? maximum : ((maximum != maximum || other > maximum) ? other : maximum);
         }
         if (lane < DS_WORDS) {
-            const float difference = maximum - idf;
-            w.features[6 + 3 * DS_WORDS + lane] =
-                static_cast<float>(1.0 + static_cast<double>(difference) / static_cast<double>(truth_words));
+            // NaN bit patterns follow x86-64 SSE (the reference's platform): a NaN operand propagates unchanged
+            // (+qNaN from the np.nan fill of :121-123), an invalid operation (inf - inf when a word count is 0)
+            // produces the default NaN, which has the sign bit set.
+            float rank;
+            if (idf != idf) {
+                rank = nan;
+            } else {
+                const float difference = maximum - idf;
+                rank = (difference != difference)
+                           ? __uint_as_float(0xffc00000u)
+                           : static_cast<float>(1.0 + static_cast<double>(difference) / static_cast<double>(truth_words));
+            }
+            w.features[6 + 3 * DS_WORDS + lane] = rank;
         }
         if (lane == 0) {  // :164-167
             w.features[0] = static_cast<float>(lq);

@@ -1,0 +1,64 @@
+"""The fused device-resident hot path: Jaccard top-k -> construct_features on the surviving (query, truth) pairs.
+
+Mirrors the two hot loops of Prediction.generate_test_predictions (predict.py:126-127 and :215-219) without the
+host round trip between them: the top-k rows written by the Jaccard kernels are consumed in HBM by the feature kernel
+(pair i = (query i // k, truth row rows[i])).  Inputs are uploaded once; `step()` only enqueues kernels.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .feature_engineering import FEATURES_COUNT, SPACE_CODE, TitleTable
+from .match_maker import TruthIndex
+
+
+class CandidatePipeline:
+    def __init__(self, workload, k, device=0, q_begin=0, q_end=None, rows_ptr=None):
+        """workload: an object with the fields of synth.make_workload.  Queries [q_begin, q_end) are this GPU's shard.
+        rows_ptr: optional device pointer of an int32[q, k] buffer owned by the caller (e.g. a torch tensor that is
+        later all-gathered); allocated here when omitted."""
+        from .distributed import slice_queries
+        self.k = k
+        self.device = device
+        q_end = workload.n_queries if q_end is None else q_end
+        self.n_queries = q_end - q_begin
+        self.n_truth = workload.n_truth
+        self.index = TruthIndex(workload.rowptr, workload.truth_idx, workload.idf32, workload.sums32, device)
+        self.truth_titles = TitleTable(workload.t_enc, workload.t_len, workload.t_counts, device)
+        self.query_titles = TitleTable(workload.q_enc[q_begin:q_end], workload.q_len[q_begin:q_end], None, device)
+        rowptr, cols, maxint = slice_queries(workload.q_rowptr, workload.q_cols, workload.q_maxint, q_begin, q_end)
+        self.d_rowptr = _lib.DeviceArray.from_host(rowptr, device)
+        self.d_cols = _lib.DeviceArray.from_host(cols if cols.shape[0] else np.zeros(1, np.int32), device)
+        self.d_maxint = _lib.DeviceArray.from_host(maxint, device)
+        self._rows = None
+        if rows_ptr is None:
+            self._rows = _lib.DeviceArray((self.n_queries, k), np.int32, device)
+            rows_ptr = self._rows.ptr
+        self.rows_ptr = rows_ptr if isinstance(rows_ptr, ctypes.c_void_p) else ctypes.c_void_p(int(rows_ptr))
+        self.d_features = _lib.DeviceArray((self.n_queries * k, FEATURES_COUNT), np.float32, device)
+
+    def enqueue_top_k(self, stream=None):
+        self.index.top_k_device(self.d_rowptr.ptr, self.d_cols.ptr, self.d_maxint.ptr, self.n_queries, self.k,
+                                self.rows_ptr, stream)
+
+    def enqueue_features(self, stream=None):
+        _lib.check(_lib.lib().ds_construct_features_indexed_device(
+            self.query_titles.handle, self.truth_titles.handle, ctypes.c_void_p(0), self.rows_ptr, 0, self.k,
+            SPACE_CODE, self.n_truth, self.n_queries * self.k, self.d_features.ptr, ctypes.c_void_p(stream or 0)),
+            "ds_construct_features_indexed_device")
+
+    def step(self, stream=None):
+        self.enqueue_top_k(stream)
+        self.enqueue_features(stream)
+
+    def sync(self, stream=None):
+        return self.index.sync(stream)
+
+    def rows(self):
+        out = np.empty((self.n_queries, self.k), dtype=np.int32)
+        _lib.check(_lib.lib().ds_memcpy_d2h(_lib.pointer(out), self.rows_ptr, out.nbytes, self.device), "d2h")
+        return out
+
+    def features(self):
+        return self.d_features.to_host()
