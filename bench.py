@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Benchmark of the doppel-speller hot path on MI355X: candidate-pairs scored per second.
+
+A step = one pass of the hot path over one batch of synthetic queries that is already resident in HBM:
+Jaccard top-k of every query against the whole truth index, then construct_features on the Q*k surviving pairs
+(metric of BASELINE.json: Q*k / (t_jaccard+topk + t_features)).  Default workload = BASELINE.json configs[1]
+(100k queries x 500k truth titles, top-10) on one GPU.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+With N > 1 every rank (one process per GPU) owns its own shard of `--queries` queries (weak scaling: the per-GPU batch
+is fixed), the truth index is replicated, and each step ends with the single all-gather of the int32 top-k rows over
+RCCL.  Rank 0 prints ONE JSON line.  torch is only imported for N > 1 (rendezvous, barrier, RCCL).
+
+Extra objects on the line:
+  roofline      Jaccard kernel: ALGORITHMIC bytes (4*sum|P_g| + 4N + 16|G_q| + 4k per query) / average
+                duration of the Jaccard launch measured with HIP events on the launch stream, against 8 TB/s.
+  cpu_baseline  the oracle (C restatement of the reference, OpenMP over all host cores) timed on a bounded sample of
+                the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*args):
+    print(*args, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(workload, k, budget_seconds):
+    """Oracle on the host cores, bounded sample: returns the dict for the JSON line."""
+    from oracle import oracle
+    oracle.build()
+    cores = oracle.num_threads()
+    pilot = min(workload.n_queries, max(2 * cores, 16))
+
+    def run(n_sample):
+        first, last = int(workload.q_rowptr[0]), int(workload.q_rowptr[n_sample])
+        t0 = time.perf_counter()
+        rows = oracle.jaccard_topk(workload.rowptr, workload.truth_idx, workload.idf32, workload.sums32,
+                                   workload.q_rowptr[:n_sample + 1], workload.q_cols[first:last],
+                                   workload.q_maxint[:n_sample], k)
+        t1 = time.perf_counter()
+        pair_q = np.repeat(np.arange(n_sample), k)
+        pair_t = rows.reshape(-1)
+        oracle.construct_features(workload.q_len[pair_q], workload.t_len[pair_t], workload.q_enc[pair_q],
+                                  workload.t_enc[pair_t], workload.t_counts[pair_t], 1, workload.n_truth)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1
+
+    tj, tf = run(pilot)
+    per_query = (tj + tf) / pilot
+    n_sample = int(min(workload.n_queries, max(pilot, budget_seconds / max(per_query, 1e-9))))
+    tj, tf = run(n_sample)
+    return {"value": n_sample * k / (tj + tf), "unit": "candidate-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"first {n_sample} queries of the workload x {workload.n_truth} truth titles, top-{k} "
+                      f"(jaccard+topk {tj:.2f}s, features {tf:.2f}s on {cores} OpenMP threads)",
+            "queries_per_s": n_sample / tj, "feature_pairs_per_s": n_sample * k / tf}
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=3)
+    parser.add_argument("--warmup", type=int, default=1)
+    parser.add_argument("--queries", type=int, default=100000, help="queries per GPU")
+    parser.add_argument("--truth", type=int, default=500000)
+    parser.add_argument("--k", type=int, default=10)
+    parser.add_argument("--seed", type=int, default=20260101)
+    parser.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget (0 disables)")
+    parser.add_argument("--check", type=int, default=64, help="queries verified against the oracle after the run")
+    args = parser.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    distributed = world > 1
+
+    import doppel_speller_amd as ds
+    from doppel_speller_amd import _lib, synth
+    from doppel_speller_amd.distributed import gather_rows
+
+    torch = None
+    rows_tensor = None
+    if distributed:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic workload: truth replicated (same seed), queries distinct per rank
+    t0 = time.perf_counter()
+    workload = synth.make_workload(args.truth, args.queries, seed=args.seed, query_seed=args.seed + 1000 * (rank + 1))
+    if rank == 0:
+        log(f"workload: {time.perf_counter() - t0:.1f}s  {synth.workload_statistics(workload)}")
+    device = local_rank
+    rows_ptr = None
+    if distributed:
+        rows_tensor = torch.empty((args.queries, args.k), dtype=torch.int32, device=f"cuda:{local_rank}")
+        rows_ptr = rows_tensor.data_ptr()
+    t0 = time.perf_counter()
+    pipeline = ds.CandidatePipeline(workload, args.k, device=device, rows_ptr=rows_ptr)
+    if rank == 0:
+        log(f"upload + index build: {time.perf_counter() - t0:.1f}s  {pipeline.index.info()}")
+    stream = torch.cuda.current_stream().cuda_stream if distributed else 0
+
+    def barrier():
+        if distributed:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+        else:
+            _lib.check(_lib.lib().ds_stream_sync(None, device), "sync")
+
+    timer_j, timer_f = _lib.Timer(device), _lib.Timer(device)
+    jaccard_ms, feature_ms = [], []
+
+    def step(record):
+        timer_j.start(stream)
+        pipeline.enqueue_top_k(stream)
+        timer_j.stop(stream)
+        timer_f.start(stream)
+        pipeline.enqueue_features(stream)
+        timer_f.stop(stream)
+        if distributed:
+            gather_rows(rows_tensor, args.queries * world)
+        if record:
+            jaccard_ms.append(timer_j.elapsed_ms())   # synchronises on the stop events
+            feature_ms.append(timer_f.elapsed_ms())
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t_begin
+    stats = pipeline.sync(stream)
+
+    if distributed:
+        worst = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        torch.distributed.all_reduce(worst, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(worst.item())
+
+    # ---- spot check against the oracle (outside the timed region)
+    checked = 0
+    if args.check > 0:
+        from oracle import oracle
+        n_check = min(args.check, args.queries)
+        rows = pipeline.rows()[:n_check]
+        last = int(workload.q_rowptr[n_check])
+        expected = oracle.jaccard_topk(workload.rowptr, workload.truth_idx, workload.idf32, workload.sums32,
+                                       workload.q_rowptr[:n_check + 1], workload.q_cols[:last],
+                                       workload.q_maxint[:n_check], args.k)
+        assert np.array_equal(rows, expected), "top-k rows differ from the oracle"
+        features = pipeline.features()[:n_check * args.k]
+        pair_q = np.repeat(np.arange(n_check), args.k)
+        pair_t = rows.reshape(-1)
+        reference = oracle.construct_features(workload.q_len[pair_q], workload.t_len[pair_t], workload.q_enc[pair_q],
+                                              workload.t_enc[pair_t], workload.t_counts[pair_t], 1, workload.n_truth)
+        assert np.array_equal(features.view(np.uint32), reference.view(np.uint32)), "features differ from the oracle"
+        checked = n_check
+
+    if rank == 0:
+        pairs_per_step = args.queries * args.k * world
+        ms_per_step = 1000.0 * elapsed / args.steps
+        bytes_jaccard = synth.algorithmic_bytes_jaccard(workload, args.k)
+        mean_j = float(np.mean(jaccard_ms))
+        achieved = bytes_jaccard / (mean_j * 1e-3) / 1e9
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_file):
+            with open(pmc_file) as handle:
+                pmc = json.load(handle)
+            if pmc.get("queries") == args.queries and pmc.get("truth") == args.truth and pmc.get("k") == args.k:
+                traffic = pmc.get("hbm_bytes_per_launch")
+        line = {
+            "metric": "candidate-pairs scored/sec (Jaccard top-k + Levenshtein), 100k x 500k titles",
+            "value": pairs_per_step / (elapsed / args.steps),
+            "unit": "candidate-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 accumulate / f64 finalise (Jaccard), u8 + f64 ratio (Levenshtein)",
+            "data": "synthetic",
+            "config": {"workload": f"1xMI355X: {args.queries} synthetic queries x {args.truth} truth titles, "
+                                   f"tri-gram vocab {workload.n_columns}, top-{args.k}"
+                       if world == 1 else
+                       f"{world}xMI355X: {args.queries} queries per GPU x {args.truth} truth titles (replicated), "
+                       f"top-{args.k}, all-gather of rows",
+                       "queries_per_gpu": args.queries, "truth_titles": args.truth, "k": args.k,
+                       "seed": args.seed, "parallelism": f"query-shard x{world}"},
+            "stages_ms": {"jaccard_topk": mean_j, "construct_features": float(np.mean(feature_ms))},
+            "queries_per_s": args.queries * world / (elapsed / args.steps),
+            "dense_path_queries": int(stats["dense_queries"]), "exact_candidates_per_query":
+                stats["exact_candidates"] / max(1, args.queries),
+            "verified_queries": checked,
+            "roofline": {"bound": "hbm", "kernel": "ds_jaccard_topk_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_jaccard, "avg_launch_ms": mean_j},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(workload, args.k, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

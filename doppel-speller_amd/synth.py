@@ -28,6 +28,7 @@ _SUFFIXES = ("limited", "ltd", "bv", "plc", "inc", "llc", "gmbh", "company")
 _SUFFIX_WEIGHTS = np.array([0.60, 0.15, 0.06, 0.05, 0.05, 0.04, 0.03, 0.02])
 ZIPF_OFFSET = 4.0
 SYLLABLES = 600
+RANDOM_WORD_FRACTION = 0.25
 SYLLABLE_EXPONENT = 1.2
 _KEYBOARD_ROWS = ("1234567890", "qwertyuiop", "asdfghjkl", "zxcvbnm")
 
@@ -67,6 +68,12 @@ class _Vocabulary:
                 chars[rows[active], (filled + j)[active]] = syllables[pick[active], j]
             filled = np.where(filled < lengths, filled + syllable_length[pick], filled)
         chars = chars[:, :width]
+        # a share of the words is spelled from uniformly random characters: rare tri-grams, so that the tri-gram
+        # vocabulary keeps growing towards its 37^3 ceiling as more of the word vocabulary gets sampled
+        random_word = rng.rand(size) < RANDOM_WORD_FRACTION
+        uniform = np.where(rng.rand(size, width) < 0.9, rng.randint(2, 28, (size, width)),
+                           rng.randint(28, 38, (size, width))).astype(np.uint8)
+        chars[random_word] = uniform[random_word]
         chars[np.arange(width)[None, :] >= lengths[:, None]] = 0
         for i, suffix in enumerate(_SUFFIXES):  # the forced head
             chars[i] = 0
@@ -194,12 +201,15 @@ def _encode(flat, offsets):
     return enc, lengths.astype(np.uint8)
 
 
-def make_workload(n_truth, n_queries, seed=DEFAULT_SEED, vocabulary_size=None):
+def make_workload(n_truth, n_queries, seed=DEFAULT_SEED, vocabulary_size=None, query_seed=None):
+    """Truth titles depend on `seed` only (identical on every rank); queries on `query_seed` (default seed + 1)."""
     rng = np.random.RandomState(seed)
     vocabulary = _Vocabulary(rng, vocabulary_size or max(20000, n_truth // 25))
     t_flat, t_off, t_words, t_word_off = _make_titles(rng, vocabulary, n_truth)
 
     # ---- queries: 60 % misspelled truth titles, 40 % fresh titles
+    title_id = rng.permutation(n_truth).astype(np.int64)
+    rng = np.random.RandomState(seed + 1 if query_seed is None else query_seed)
     n_edited = int(round(0.6 * n_queries))
     source = rng.randint(0, n_truth, n_edited)
     truth_strings_needed = _to_strings(
@@ -261,7 +271,7 @@ def make_workload(n_truth, n_queries, seed=DEFAULT_SEED, vocabulary_size=None):
         rowptr=rowptr, truth_idx=truth_idx, idf32=idf32, idf64=idf64, sums32=sums32,
         q_rowptr=q_rowptr, q_cols=q_col.astype(np.int32), q_maxint=q_maxint,
         t_enc=t_enc, t_len=t_len, t_counts=t_counts, q_enc=q_enc, q_len=q_len,
-        title_id=rng.permutation(n_truth).astype(np.int64), actual_row=actual,
+        title_id=title_id, actual_row=actual,
         t_flat=t_flat, t_off=t_off, q_flat=q_flat, q_off=q_off)
 
 
