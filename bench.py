@@ -207,7 +207,8 @@ def main():
             "queries_per_s": args.queries * world / (elapsed / args.steps),
             "dense_path_queries": int(stats["dense_queries"]), "exact_candidates_per_query":
                 stats["exact_candidates"] / max(1, args.queries),
-            "verified_queries": checked,
+            "verified_queries": checked, "selections_per_query": stats["selections"] / max(1, args.queries),
+            "phase_cycles": stats["phase_cycles"],
             "roofline": {"bound": "hbm", "kernel": "ds_jaccard_topk_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_jaccard, "avg_launch_ms": mean_j},

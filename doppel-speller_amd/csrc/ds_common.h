@@ -89,6 +89,7 @@ struct ds_index {
     ds::DeviceBuffer<int32_t> control;     // [16] work-queue head, slow-list length, error count, counters
     ds::DeviceBuffer<int32_t> status;      // per-query status of the last call (grown on demand)
     ds::DeviceBuffer<int32_t> slow_list;   // query ids routed to the exact dense kernel
+    ds::DeviceBuffer<unsigned long long> phase;  // diagnostic phase timers (DS_PHASE_TIMERS=1)
     hipStream_t stream = nullptr;          // used by the host-pointer entry points
     int64_t last_queries = 0;
 };

@@ -22,6 +22,7 @@
 //       jaccard row in HBM, radix select of the k-th float32 value, descending collect) for the queries the fast
 //       kernel cannot bound: more than 256 columns, maxint <= 0, fewer than k positive rows, massive ties.
 #include <cfloat>
+#include <cstdlib>
 
 #include "ds_common.h"
 
@@ -40,6 +41,7 @@ struct JaccardArgs {
     int32_t *control;
     int32_t *slow_list;
     double *slow_scratch;
+    unsigned long long *phase;  // nullable: per-phase shader-clock sums (diagnostics, DS_PHASE_TIMERS=1)
     int64_t n_truth;
     int64_t n_columns;
     int64_t n_queries;
@@ -118,8 +120,19 @@ __device__ uint32_t radix_select_kth(const uint32_t *cand_key, int m, int k, uin
     return prefix;
 }
 
+// Diagnostic phase timers: thread 0 adds the shader-clock delta since its previous stamp to phase[slot].
+#define DS_STAMP(slot)                                                     \
+    do {                                                                   \
+        if (a.phase != nullptr && tid == 0) {                              \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+            atomicAdd(&a.phase[slot], now_ - stamp_);                      \
+            stamp_ = now_;                                                 \
+        }                                                                  \
+    } while (0)
+
 __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a)
 {
+    unsigned long long stamp_ = a.phase != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
     extern __shared__ __align__(16) unsigned char lds[];
     float *scores = reinterpret_cast<float *>(lds);
     uint32_t *cand_key = reinterpret_cast<uint32_t *>(lds + kOffKey);
@@ -174,6 +187,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             continue;
         }
 
+        DS_STAMP(0);
         const float maxint32 = static_cast<float>(maxint);
         // |float32 approximate jaccard - exact jaccard| <= margin (see DESIGN.md "error margin of the prefilter")
         const double margin = (6.0 * n + 64.0) * 5.9604644775390625e-08;
@@ -190,6 +204,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                 list_end[tid] = ptr_row[cols[tid] + 1];
             }
             __syncthreads();
+            DS_STAMP(1);
             // (1) scatter: order-free float32 LDS atomics; padding entries hit the trash slot scores[kTile]
             for (int j = 0; j < n; ++j) {
                 const uint32_t begin = list_begin[j], end = list_end[j];
@@ -203,6 +218,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                 }
             }
             __syncthreads();
+            DS_STAMP(2);
             // (2) scan (and re-zero) the tile
             const int64_t tile_base = static_cast<int64_t>(b) << kTileLog2;
             const int64_t rows_left = a.n_truth - tile_base;
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     }
                 }
                 __syncthreads();
+                DS_STAMP(3);
                 r0 = r1;
                 if (ctrl[kLOverflow]) { slow = true; break; }
                 const int m = ctrl[kLCount];
@@ -303,6 +320,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     const int kept = ctrl[kLCount];
                     if (kept > kSelectTrigger) { slow = true; break; }  // massive ties: use the dense kernel
                     next_select = min(kSelectTrigger, max(2 * kept, max(4 * k, 64)));
+                    DS_STAMP(4);
                 }
             }
         }
@@ -411,6 +429,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                 atomicAdd(&a.control[kCtlSelects], selects);
             }
             __syncthreads();
+            DS_STAMP(5);
         } else {
             if (tid == 0) {
                 a.status[q] = kQuerySlow;
@@ -419,6 +438,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             for (int i = tid * 4; i < kScoreFloats; i += kThreads * 4)
                 *reinterpret_cast<float4 *>(&scores[i]) = make_float4(0.f, 0.f, 0.f, 0.f);
             __syncthreads();
+            DS_STAMP(6);
         }
     }
 }
@@ -597,6 +617,12 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     args.control = index->control.ptr;
     args.slow_list = index->slow_list.ptr;
     args.slow_scratch = index->slow_scratch.ptr;
+    args.phase = nullptr;
+    if (const char *timers = getenv("DS_PHASE_TIMERS"); timers != nullptr && timers[0] == '1') {
+        if (index->phase.count == 0 && index->phase.allocate(16) != DS_OK) return DS_E_HIP;
+        DS_HIP(hipMemsetAsync(index->phase.ptr, 0, 16 * sizeof(unsigned long long), stream));
+        args.phase = index->phase.ptr;
+    }
     args.n_truth = index->n_truth;
     args.n_columns = index->n_columns;
     args.n_queries = Q;
@@ -616,7 +642,7 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     return DS_OK;
 }
 
-static int collect(ds_index *index, hipStream_t stream, int64_t stats[4])
+static int collect(ds_index *index, hipStream_t stream, int64_t stats[16])
 {
     DS_REQUIRE(index != nullptr, "ds_jaccard_sync: null index");
     DS_HIP(hipSetDevice(index->device));
@@ -628,6 +654,12 @@ static int collect(ds_index *index, hipStream_t stream, int64_t stats[4])
         stats[1] = control[kCtlErrors];
         stats[2] = control[kCtlExact];
         stats[3] = control[kCtlSelects];
+        for (int i = 4; i < 16; ++i) stats[i] = 0;
+        if (index->phase.count) {
+            unsigned long long phase[16];
+            DS_HIP(hipMemcpy(phase, index->phase.ptr, sizeof(phase), hipMemcpyDeviceToHost));
+            for (int i = 0; i < 8; ++i) stats[4 + i] = static_cast<int64_t>(phase[i]);
+        }
     }
     if (control[kCtlErrors] != 0 && index->last_queries > 0) {
         std::vector<int32_t> status(static_cast<size_t>(index->last_queries));
@@ -656,7 +688,7 @@ int ds_jaccard_topk_device(ds_index *index, const int64_t *d_q_rowptr, const int
     return ds::launch(index, d_q_rowptr, d_q_cols, d_q_maxint, Q, k, d_out_rows, static_cast<hipStream_t>(stream));
 }
 
-int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[4])
+int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[16])
 {
     return ds::collect(index, static_cast<hipStream_t>(stream), stats);
 }

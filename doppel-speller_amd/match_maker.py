@@ -90,10 +90,11 @@ class TruthIndex:
             ctypes.c_void_p(stream or 0)), "ds_jaccard_topk_device")
 
     def sync(self, stream=None):
-        stats = (ctypes.c_int64 * 4)()
+        stats = (ctypes.c_int64 * 16)()
         _lib.check(_lib.lib().ds_jaccard_sync(self.handle, ctypes.c_void_p(stream or 0), stats), "ds_jaccard_sync")
+        names = ("setup", "list_pointers", "scatter", "scan", "select", "exact", "dense_handover")
         return {"dense_queries": stats[0], "error_queries": stats[1], "exact_candidates": stats[2],
-                "selections": stats[3]}
+                "selections": stats[3], "phase_cycles": dict(zip(names, list(stats)[4:11]))}
 
     def close(self):
         if self.handle:

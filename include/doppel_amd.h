@@ -70,8 +70,9 @@ int ds_jaccard_topk_device(ds_index *index, const int64_t *d_q_rowptr, const int
                            const double *d_q_maxint, int64_t Q, int32_t k, int32_t *d_out_rows, void *stream);
 /* Waits for `stream`, returns the status of the last ds_jaccard_topk_device on this index;
  * stats[0]=queries answered by the exact dense kernel, stats[1]=queries in error, stats[2]=candidates evaluated
- * exactly (total), stats[3]=threshold selections run (total). */
-int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[4]);
+ * exactly (total), stats[3]=threshold selections run (total), stats[4..11]=shader-clock sums per kernel phase
+ * (setup, list pointers, scatter, scan, select, exact stage, dense hand-over; only with DS_PHASE_TIMERS=1). */
+int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[16]);
 
 /* ---- Levenshtein / features:  fast_levenshtein_ratio + construct_features (feature_engineering.py:25-169) ------- */
 /* The 9-argument gufunc of feature_engineering.py:69-80 without the `dummy` argument: rows of q_enc / t_enc are
