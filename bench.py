@@ -208,7 +208,11 @@ def main():
             "dense_path_queries": int(stats["dense_queries"]), "exact_candidates_per_query":
                 stats["exact_candidates"] / max(1, args.queries),
             "verified_queries": checked, "selections_per_query": stats["selections"] / max(1, args.queries),
-            "phase_cycles": stats["phase_cycles"],
+            "phase_cycles": stats["phase_cycles"], "dense_reasons": stats["dense_reasons"],
+            "tiles": {"sparse": stats["sparse_tiles"], "dense": stats["dense_tiles"]},
+            "skipped_columns_per_query": stats["skipped_columns"] / max(1, args.queries),
+            "refine": {"calls": stats["refines"], "raw_entries": stats["raw_entries"],
+                       "with_binary_search": stats["refines_with_search"]},
             "roofline": {"bound": "hbm", "kernel": "ds_jaccard_topk_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_jaccard, "avg_launch_ms": mean_j},

@@ -17,10 +17,16 @@ namespace ds {
 constexpr int kTileLog2 = 15;
 constexpr int kTile = 1 << kTileLog2;        // truth rows per tile: one float32 score per row fills 128 KiB of LDS
 constexpr int kSentinel = kTile;             // padding entry of a posting quad: lands in the trash slot scores[kTile]
-constexpr int kThreads = 1024;               // one 16-wave workgroup per CU
-constexpr int kMaxQueryColumns = 256;        // titles are <= 255 chars => <= 253 tri-grams (settings.py:68)
-constexpr int kCandidates = 3072;            // capacity of the per-query candidate buffer in LDS
-constexpr int kLooseStep = 1024;             // rows scanned between two capacity checks while no threshold exists
+constexpr int kThreads = 512;                // one 8-wave workgroup per CU (<= 256 VGPRs per lane)
+constexpr int kMaxQueryColumns = 128;        // fast-path limit (example data: p99 50, max 96 tri-grams per title)
+constexpr int kCandidates = 1792;            // capacity of the per-query candidate buffer in LDS
+constexpr int kLooseStep = 512;              // rows scanned between two capacity checks while no threshold exists
+constexpr int kPtrTiles = 8;                 // tiles whose list pointers are cached in LDS at a time
+constexpr int kItemQuads = 256;              // a work item = up to 256 posting quads of one (tile, column) list
+constexpr int kMaxItems = 512;               // work items per (query, tile); more => dense kernel
+constexpr int kSignatureBits = 128;          // densest columns whose membership is kept as a per-row bit (uint4)
+constexpr int kSignatureWords = kSignatureBits / 32;
+constexpr int kControlWords = 32;            // int32 control block in HBM (queue heads, counters)
 constexpr int kSlowSlots = 64;               // concurrent queries of the exact dense kernel (scratch = slots*N*8 B)
 
 enum QueryStatus : int32_t { kQueryDone = 0, kQuerySlow = 1, kQueryErrorTopN = 2, kQueryErrorArg = 3 };
@@ -81,16 +87,22 @@ struct ds_index {
     int device = 0;
     int64_t n_truth = 0, n_columns = 0, nnz = 0, n_tiles = 0, n_quads = 0;
     float sums_min = 0.f;
-    ds::DeviceBuffer<uint32_t> tile_ptr;   // [n_tiles][n_columns + 1], unit = quads of 4 postings
-    ds::DeviceBuffer<uint16_t> postings;   // [n_quads * 4] tile-local truth rows, kSentinel-padded per (tile, column)
+    ds::DeviceBuffer<uint32_t> col_ptr;    // [n_columns][n_tiles + 1], unit = quads of 4 postings (column-major)
+    ds::DeviceBuffer<uint16_t> postings;   // [n_quads * 4] tile-local truth rows, kSentinel-padded per (column, tile)
+    ds::DeviceBuffer<uint16_t> posting_sums; // [n_quads * 4] bfloat16 (truncated = lower bound) of sums32[row], same order
     ds::DeviceBuffer<float> idf32;         // [n_columns]
     ds::DeviceBuffer<float> sums32;        // [n_truth]
+    ds::DeviceBuffer<float> tile_sums_min; // [n_tiles] min(sums32) over the rows of each tile
+    ds::DeviceBuffer<uint32_t> signature;  // [n_truth][4] bit g = row is in the posting list of the g-th densest column
+    ds::DeviceBuffer<int8_t> sig_column;   // [n_columns] signature bit of a column, -1 for all but the 128 densest
     ds::DeviceBuffer<double> slow_scratch; // [kSlowSlots][n_truth] float64 jaccard rows of the exact dense kernel
     ds::DeviceBuffer<int32_t> control;     // [16] work-queue head, slow-list length, error count, counters
     ds::DeviceBuffer<int32_t> status;      // per-query status of the last call (grown on demand)
     ds::DeviceBuffer<int32_t> slow_list;   // query ids routed to the exact dense kernel
     ds::DeviceBuffer<unsigned long long> phase;  // diagnostic phase timers (DS_PHASE_TIMERS=1)
     hipStream_t stream = nullptr;          // used by the host-pointer entry points
+    int compute_units = 256;
+    bool attributes_set = false;
     int64_t last_queries = 0;
 };
 

@@ -8,19 +8,23 @@
 //                           threshold = float64(m) - float64(float32(1e-6));
 //                           result = the k LARGEST ROW INDEXES among {t : jaccard[t] >= threshold}, descending.
 //
-// Two kernels (DESIGN.md section "Jaccard kernels"):
-//   ds_jaccard_topk_kernel   one 1024-thread workgroup per query pulled from a work queue.  Per tile of 32768 truth
-//       rows: (1) scatter -- every posting of the query's columns adds idf32[g] into a float32 score tile in LDS with
-//       order-free LDS atomics (approximate: the float32 rounding depends on the order); (2) scan -- rows whose
-//       approximate jaccard can still reach the running k-th largest value (minus a rigorous error margin) are
-//       appended to a candidate buffer; a radix select over the buffer tightens the running value.  After the last
-//       tile only the surviving candidates (k + a few) are evaluated EXACTLY: membership of the row in each query
-//       column's posting list by binary search, float32 sum in the reference's column order, float64 finalise,
-//       then the reference's threshold/arg-select.  Results are bit-exact; the approximation only decides where the
+// Two kernels:
+//   ds_jaccard_topk_kernel   one 1024-thread workgroup per query pulled from a work queue.  The truth rows are
+//       visited tile by tile (32768 rows = one float32 score tile in LDS).  Scores are accumulated with order-free
+//       LDS atomics, i.e. only APPROXIMATELY (the reference's float32 rounding depends on the column order); rows
+//       whose approximate jaccard can still reach the running k-th largest value minus a rigorous error margin
+//       become candidates; a radix select over the candidate buffer tightens the running value.  Once a running
+//       value exists, columns whose total IDF cannot lift a row over it on their own ("non-essential", the
+//       MaxScore rule of top-k retrieval) are no longer traversed: their IDF mass enters the test as an upper bound.
+//       Tiles with few essential postings are handled sparsely (scatter, then an exchange sweep over the same
+//       postings that collects and re-zeroes the touched rows) instead of scanning all 32768 scores.
+//       After the last tile the surviving candidates are evaluated EXACTLY: membership of the row in each query
+//       column's posting list by binary search, float32 sum in the reference's column order, float64 finalise, then
+//       the reference's threshold / arg-select.  Results are bit-exact; the approximation only decides where the
 //       exact arithmetic is spent.
 //   ds_jaccard_dense_kernel  the literal algorithm (ordered scatter with a barrier per column, dense float64
 //       jaccard row in HBM, radix select of the k-th float32 value, descending collect) for the queries the fast
-//       kernel cannot bound: more than 256 columns, maxint <= 0, fewer than k positive rows, massive ties.
+//       kernel cannot bound: more than 128 columns, maxint <= 0, fewer than k positive rows, massive ties.
 #include <cfloat>
 #include <cstdlib>
 
@@ -29,10 +33,14 @@
 namespace ds {
 
 struct JaccardArgs {
-    const uint32_t *tile_ptr;
+    const uint32_t *col_ptr;
     const uint16_t *postings;
+    const uint16_t *posting_sums;
     const float *idf32;
     const float *sums32;
+    const float *tile_sums_min;
+    const uint4 *signature;
+    const int8_t *sig_column;
     const int64_t *q_rowptr;
     const int32_t *q_cols;
     const double *q_maxint;
@@ -47,28 +55,43 @@ struct JaccardArgs {
     int64_t n_queries;
     int32_t n_tiles;
     int32_t k;
+    int32_t sparse_quads;       // tiles with at most this many essential quads are handled sparsely
     float sums_min;
 };
 
 // control words in HBM
-enum { kCtlQueue = 0, kCtlSlowCount = 1, kCtlErrors = 2, kCtlExact = 3, kCtlSelects = 4, kCtlSlowQueue = 5 };
+enum { kCtlQueue = 0, kCtlSlowCount = 1, kCtlErrors = 2, kCtlExact = 3, kCtlSelects = 4, kCtlSlowQueue = 5,
+       kCtlSparseTiles = 6, kCtlDenseTiles = 7, kCtlSkippedColumns = 8, kCtlReason = 9 /* 9..14 */,
+       kCtlRefines = 16, kCtlRawEntries = 17, kCtlSearches = 18 };
 
 // LDS carve-up of the fast kernel (bytes)
 constexpr int kScoreFloats = kTile + 64;  // + trash slot for the padding entries of a quad
-constexpr int kOffKey = kScoreFloats * 4;
-constexpr int kOffRow = kOffKey + kCandidates * 4;
+constexpr int kOffLo = kScoreFloats * 4;
+constexpr int kOffRow = kOffLo + kCandidates * 4;
 constexpr int kOffCols = kOffRow + kCandidates * 4;
 constexpr int kOffIdf = kOffCols + kMaxQueryColumns * 4;
-constexpr int kOffBegin = kOffIdf + kMaxQueryColumns * 4;
+constexpr int kOffRank = kOffIdf + kMaxQueryColumns * 4;
+constexpr int kOffOrder = kOffRank + kMaxQueryColumns * 4;
+constexpr int kOffMass = kOffOrder + kMaxQueryColumns * 4;
+constexpr int kOffSigBit = kOffMass + kMaxQueryColumns * 4;
+constexpr int kOffBitIdf = kOffSigBit + kMaxQueryColumns * 4;
+constexpr int kOffFixed = kOffBitIdf + kSignatureBits * 4;
+constexpr int kOffBegin = kOffFixed + kMaxQueryColumns * 4;
 constexpr int kOffEnd = kOffBegin + kMaxQueryColumns * 4;
-constexpr int kOffHist = kOffEnd + kMaxQueryColumns * 4;
+constexpr int kOffPtr = kOffEnd + kMaxQueryColumns * 4;
+constexpr int kOffItems = kOffPtr + kMaxQueryColumns * (kPtrTiles + 1) * 4;
+constexpr int kOffHist = kOffItems + kMaxItems * 2;
 constexpr int kOffCtrl = kOffHist + 256 * 4;
-constexpr int kFastLdsBytes = kOffCtrl + 64;
+constexpr int kFastLdsBytes = kOffCtrl + 128;
 static_assert(kFastLdsBytes <= 160 * 1024, "LDS budget of one CU exceeded");
+static_assert(kMaxQueryColumns == 128 && kItemQuads == 256, "item encoding: 7 bits column, 5 bits chunk");
+constexpr int kKeep = (kCandidates + kThreads - 1) / kThreads;  // candidate entries a thread holds while compacting
 constexpr int kSelectTrigger = kCandidates - kLooseStep;
+constexpr int kWaves = kThreads / 64;
 
 // LDS control words
-enum { kLQuery = 0, kLCount, kLOverflow, kLDigit, kLRemain, kLCoef, kLPre, kLCut, kLKth0, kLKth1, kLBad };
+enum { kLQuery = 0, kLCount, kLOverflow, kLDigit, kLRemain, kLCoef, kLPre, kLCut, kLKth0, kLKth1, kLBad, kLItems,
+       kLQuads, kLNonEssential, kLMass, kLUnsigned, kLSigMask /* 4 words */, kLEnd = kLSigMask + 4 };
 
 __device__ __forceinline__ float round_down_positive(double x)
 {
@@ -77,8 +100,24 @@ __device__ __forceinline__ float round_down_positive(double x)
     return f;
 }
 
-// k-th largest key of cand_key[0..m) (m >= k) by a 4 x 8-bit radix select; result in ctrl[kLDigit] history -> return.
-__device__ uint32_t radix_select_kth(const uint32_t *cand_key, int m, int k, uint32_t *hist, volatile int32_t *ctrl)
+__device__ __forceinline__ float round_up_positive(double x)
+{
+    float f = static_cast<float>(x);
+    if (static_cast<double>(f) < x) f = __uint_as_float(__float_as_uint(f) + 1u);
+    return f;
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t value, int lane)
+{
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t other = __shfl_up(value, d);
+        if (lane >= d) value += other;
+    }
+    return value;
+}
+
+// k-th largest key of keys[0..m) (m >= k) by a 4 x 8-bit radix select.  All threads of the workgroup call it.
+__device__ uint32_t radix_select_kth(const uint32_t *keys, int m, int k, uint32_t *hist, volatile int32_t *ctrl)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     uint32_t prefix = 0, mask = 0;
@@ -87,7 +126,7 @@ __device__ uint32_t radix_select_kth(const uint32_t *cand_key, int m, int k, uin
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         for (int i = tid; i < m; i += kThreads) {
-            const uint32_t key = cand_key[i];
+            const uint32_t key = keys[i];
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
@@ -95,11 +134,7 @@ __device__ uint32_t radix_select_kth(const uint32_t *cand_key, int m, int k, uin
             const int b0 = 255 - 4 * lane;
             const uint32_t c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
             const uint32_t local = c0 + c1 + c2 + c3;
-            uint32_t inclusive = local;
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t other = __shfl_up(inclusive, d);
-                if (lane >= d) inclusive += other;
-            }
+            const uint32_t inclusive = wave_inclusive_scan(local, lane);
             const uint32_t exclusive = inclusive - local;
             const uint32_t want = static_cast<uint32_t>(remaining);
             if (want > exclusive && want <= inclusive) {
@@ -120,6 +155,92 @@ __device__ uint32_t radix_select_kth(const uint32_t *cand_key, int m, int k, uin
     return prefix;
 }
 
+// Everything the scan / collect phases need to turn an approximate score into a candidate.
+struct Bounds {
+    float coef;      // cut / (1 + cut), rounded down: row qualifies only if s + mass >= coef * (sums + maxint32)
+    float pre;       // row-independent lower bound of the right-hand side (uses min(sums))
+    float mass;      // upper bound of what the skipped (non-essential) columns can add to any score
+    float maxint32;
+};
+
+// Loose test: can the row still qualify if every skipped (non-essential) column matched as well?
+__device__ __forceinline__ bool may_qualify(float s, float sums, const Bounds &b)
+{
+    return s + b.mass >= b.coef * (sums + b.maxint32);
+}
+
+// Tight test on a complete approximate score + the radix key (float32 approximate jaccard) of a candidate.
+__device__ __forceinline__ bool candidate_key(float s, float sums, const Bounds &b, uint32_t &key)
+{
+    if (!(s >= b.coef * (sums + b.maxint32))) return false;
+    const float denominator = sums + (b.maxint32 - s);
+    const float approx = s / denominator;
+    key = (denominator > 0.f && approx == approx) ? __float_as_uint(approx) : 0x7f800000u;
+    return true;
+}
+
+// What the skipped columns of a tile look like to the completion step.
+struct Skipped {
+    int count;           // ranks 0..count-1 of the ascending-IDF order are skipped
+    uint32_t sig_mask[kSignatureWords];  // signature bits of the skipped columns that have one
+    int without_bit;     // skipped columns without a signature bit (need a binary search)
+};
+
+// Adds what the skipped columns contribute to row t (tile-local `local`): one signature load for the dense columns,
+// a binary search in the (column, tile) sub-list for the others.  Approximate (order-free) like the scatter itself.
+// Called by the few lanes whose row passed the loose test.
+__device__ __forceinline__ float complete_score(float s, uint4 signature, uint32_t local, const Skipped &skipped,
+                                                int bt, const int32_t *order, const int32_t *sig_bit,
+                                                const float *bit_idf, const uint32_t *ptr_cache, const float *idf,
+                                                const uint16_t *postings)
+{
+    const uint32_t words[kSignatureWords] = {signature.x, signature.y, signature.z, signature.w};
+#pragma unroll
+    for (int w = 0; w < kSignatureWords; ++w) {
+        uint32_t bits = words[w] & skipped.sig_mask[w];
+        while (bits) {
+            s += bit_idf[w * 32 + __ffs(bits) - 1];
+            bits &= bits - 1u;
+        }
+    }
+    if (skipped.without_bit > 0) {
+        for (int r = 0; r < skipped.count; ++r) {
+            const int j = order[r];
+            if (sig_bit[j] >= 0) continue;
+            uint32_t lo = ptr_cache[j * (kPtrTiles + 1) + bt] * 4u;
+            const uint32_t end = ptr_cache[j * (kPtrTiles + 1) + bt + 1] * 4u;
+            uint32_t hi = end;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (postings[mid] < local) lo = mid + 1; else hi = mid;
+            }
+            if (lo < end && postings[lo] == local) s += idf[j];
+        }
+    }
+    return s;
+}
+
+// Wave-aggregated append to the candidate buffer.  Must be called by all active lanes of the wave together.
+__device__ __forceinline__ void append_candidate(bool pass, uint32_t key, int32_t row, uint32_t *cand_key,
+                                                 int32_t *cand_row, volatile int32_t *ctrl, int lane)
+{
+    const unsigned long long votes = __ballot(pass);
+    if (votes == 0) return;
+    const int leader = __ffsll(votes) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(const_cast<int32_t *>(&ctrl[kLCount]), __popcll(votes));
+    base = __shfl(base, leader);
+    if (pass) {
+        const int slot = base + __popcll(votes & ((1ull << lane) - 1ull));
+        if (slot < kCandidates) {
+            cand_key[slot] = key;
+            cand_row[slot] = row;
+        } else {
+            ctrl[kLOverflow] = 1;
+        }
+    }
+}
+
 // Diagnostic phase timers: thread 0 adds the shader-clock delta since its previous stamp to phase[slot].
 #define DS_STAMP(slot)                                                     \
     do {                                                                   \
@@ -135,19 +256,29 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
     unsigned long long stamp_ = a.phase != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
     extern __shared__ __align__(16) unsigned char lds[];
     float *scores = reinterpret_cast<float *>(lds);
-    uint32_t *cand_key = reinterpret_cast<uint32_t *>(lds + kOffKey);
+    uint32_t *cand_key = reinterpret_cast<uint32_t *>(lds + kOffLo);
     int32_t *cand_row = reinterpret_cast<int32_t *>(lds + kOffRow);
     int32_t *cols = reinterpret_cast<int32_t *>(lds + kOffCols);
     float *idf = reinterpret_cast<float *>(lds + kOffIdf);
+    int32_t *rank = reinterpret_cast<int32_t *>(lds + kOffRank);     // position of column j in ascending-IDF order
+    int32_t *order = reinterpret_cast<int32_t *>(lds + kOffOrder);   // inverse: column at position r
+    float *mass_upto = reinterpret_cast<float *>(lds + kOffMass);    // [r] = IDF mass of ranks 0..r, rounded up
+    int32_t *sig_bit = reinterpret_cast<int32_t *>(lds + kOffSigBit);  // signature bit of column j or -1
+    float *bit_idf = reinterpret_cast<float *>(lds + kOffBitIdf);     // IDF of the query column owning signature bit g
+    uint32_t *fixed = reinterpret_cast<uint32_t *>(lds + kOffFixed);  // idf[j] in the query's fixed-point scale
+    uint32_t *iscores = reinterpret_cast<uint32_t *>(lds);           // the score tile holds fixed-point sums
     uint32_t *list_begin = reinterpret_cast<uint32_t *>(lds + kOffBegin);
     uint32_t *list_end = reinterpret_cast<uint32_t *>(lds + kOffEnd);
+    uint32_t *ptr_cache = reinterpret_cast<uint32_t *>(lds + kOffPtr);  // [column][kPtrTiles + 1]
+    uint16_t *items = reinterpret_cast<uint16_t *>(lds + kOffItems);
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + kOffHist);
     volatile int32_t *ctrl = reinterpret_cast<volatile int32_t *>(lds + kOffCtrl);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.k;
-    const int64_t ptr_stride = a.n_columns + 1;
+    const int64_t ptr_stride = static_cast<int64_t>(a.n_tiles) + 1;
     const uint2 *quads = reinterpret_cast<const uint2 *>(a.postings);
+    const uint2 *sums_quads = reinterpret_cast<const uint2 *>(a.posting_sums);
 
     for (int i = tid * 4; i < kScoreFloats; i += kThreads * 4)
         *reinterpret_cast<float4 *>(&scores[i]) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -162,19 +293,24 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
         }
         __syncthreads();
         const int64_t q = ctrl[kLQuery];
-        if (q >= a.n_queries) break;  // exit condition reached by every wave: the queue only grows
+        if (q >= a.n_queries) break;  // exit condition reached by every wave: the queue head only grows
 
         const int64_t qbase = a.q_rowptr[q];
         const int64_t n64 = a.q_rowptr[q + 1] - qbase;
         const double maxint = a.q_maxint[q];
         bool slow = n64 > kMaxQueryColumns || n64 < 0 || !(maxint > 0.0) || !(maxint < 1e30);
+        int reason = slow ? 0 : -1;  // why the query is handed to the dense kernel (diagnostics)
         const int n = slow ? 0 : static_cast<int>(n64);
         if (tid < n) {
             const int32_t column = a.q_cols[qbase + tid];
             const bool bad = column < 0 || column >= a.n_columns;
             if (bad) ctrl[kLBad] = 1;
             cols[tid] = bad ? 0 : column;
-            idf[tid] = bad ? 0.f : a.idf32[column];
+            const float value = bad ? 0.f : a.idf32[column];
+            const int bit = bad ? -1 : static_cast<int>(a.sig_column[column]);
+            idf[tid] = value;
+            sig_bit[tid] = bit;
+            if (bit >= 0) bit_idf[bit] = value;
         }
         __syncthreads();
         if (ctrl[kLBad]) {
@@ -186,159 +322,356 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             __syncthreads();
             continue;
         }
+        // ascending-IDF order of the query's columns and the IDF mass of every prefix of that order
+        if (tid < n) {
+            const float mine = idf[tid];
+            int r = 0;
+            double below = 0.0;
+            for (int i = 0; i < n; ++i) {
+                const float other = idf[i];
+                const bool first = other < mine || (other == mine && i <= tid);
+                r += first && i != tid;
+                below += first ? static_cast<double>(other) : 0.0;
+            }
+            rank[tid] = r;
+            order[r] = tid;
+            mass_upto[r] = round_up_positive(below * (1.0 + 3.814697265625e-06));
+        }
 
-        DS_STAMP(0);
         const float maxint32 = static_cast<float>(maxint);
-        // |float32 approximate jaccard - exact jaccard| <= margin (see DESIGN.md "error margin of the prefilter")
-        const double margin = (6.0 * n + 64.0) * 5.9604644775390625e-08;
-        float coef = 0.f, pre = FLT_MIN, cut = 0.f;  // scan test: s >= pre && s >= coef * (sums[t] + maxint32)
+        __syncthreads();
+        // Scores are accumulated in unsigned fixed point (LDS integer atomics run ~14x faster than ds_add_f32 on
+        // gfx950 and are order-independent): one unit = total/2^30 where total >= every reachable score.
+        const float total_mass = n > 0 ? fmaxf(maxint32, mass_upto[n - 1]) : maxint32;
+        const float to_fixed = 1073741824.f / total_mass, from_fixed = total_mass * 9.313225746154785e-10f;
+        if (tid < n) fixed[tid] = max(1u, static_cast<uint32_t>(idf[tid] * to_fixed + 0.5f));
+        // |approximate jaccard - exact jaccard| <= margin (DESIGN.md "error margin of the prefilter"):
+        // float32 evaluation + quantisation of n terms to 2^-30 of the total
+        const double margin = (6.0 * n + 64.0) * 5.9604644775390625e-08 + n * 3.725290298461914e-09;
+        Bounds bounds{0.f, FLT_MIN, 0.f, maxint32};
+        float cut = 0.f, pending_mass = 0.f;  // mass of the columns skipped from the NEXT tile on
+        uint32_t pending_sig_mask[kSignatureWords] = {0u, 0u, 0u, 0u};
+        int pending_without_bit = 0;
+        int non_essential = 0;
         bool tight = false;
         int next_select = max(4 * k, 64);
         if (next_select > kSelectTrigger) next_select = kSelectTrigger;
-        int selects = 0;
+        int selects = 0, sparse_tiles = 0, dense_tiles = 0;
+        DS_STAMP(0);
 
         for (int b = 0; b < a.n_tiles && !slow; ++b) {
-            const uint32_t *ptr_row = a.tile_ptr + static_cast<int64_t>(b) * ptr_stride;
-            if (tid < n) {
-                list_begin[tid] = ptr_row[cols[tid]];
-                list_end[tid] = ptr_row[cols[tid] + 1];
+            const int bt = b % kPtrTiles;
+            if (bt == 0) {  // list pointers of the next kPtrTiles tiles for every query column: one coalesced burst
+                __syncthreads();
+                const int width = min(kPtrTiles, a.n_tiles - b) + 1;
+                for (int e = tid; e < n * (kPtrTiles + 1); e += kThreads) {
+                    const int j = e / (kPtrTiles + 1), i = e % (kPtrTiles + 1);
+                    ptr_cache[e] = i < width ? a.col_ptr[static_cast<int64_t>(cols[j]) * ptr_stride + b + i] : 0u;
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            DS_STAMP(1);
-            // (1) scatter: order-free float32 LDS atomics; padding entries hit the trash slot scores[kTile]
-            for (int j = 0; j < n; ++j) {
-                const uint32_t begin = list_begin[j], end = list_end[j];
-                const float value = idf[j];
-                for (uint32_t i = begin + tid; i < end; i += kThreads) {
-                    const uint2 quad = quads[i];
-                    atomicAdd(&scores[quad.x & 0xffffu], value);
-                    atomicAdd(&scores[quad.x >> 16], value);
-                    atomicAdd(&scores[quad.y & 0xffffu], value);
-                    atomicAdd(&scores[quad.y >> 16], value);
+            // ---- work items of this tile: (column, chunk of kItemQuads quads) for every essential column
+            bounds.mass = pending_mass;  // what this tile's scores do NOT contain; fixed until the tile is done
+            const Skipped skipped{non_essential,
+                                  {pending_sig_mask[0], pending_sig_mask[1], pending_sig_mask[2], pending_sig_mask[3]},
+                                  pending_without_bit};
+            if (wave == 0) {
+                uint32_t length[2], count[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = lane + 64 * h;
+                    uint32_t begin = 0, end = 0;
+                    if (j < n && rank[j] >= non_essential) {
+                        begin = ptr_cache[j * (kPtrTiles + 1) + bt];
+                        end = ptr_cache[j * (kPtrTiles + 1) + bt + 1];
+                    }
+                    list_begin[j] = begin;
+                    list_end[j] = end;
+                    length[h] = end - begin;
+                    count[h] = (length[h] + kItemQuads - 1) / kItemQuads;
+                }
+                const uint32_t scan0 = wave_inclusive_scan(count[0], lane);
+                const uint32_t total0 = __shfl(scan0, 63);
+                const uint32_t scan1 = wave_inclusive_scan(count[1], lane);
+                const uint32_t total1 = __shfl(scan1, 63);
+                const uint32_t n_items = total0 + total1;
+                uint32_t quads_here = length[0] + length[1];
+                for (int d = 32; d > 0; d >>= 1) quads_here += __shfl_xor(quads_here, d);
+                if (n_items <= kMaxItems) {
+                    uint32_t at = scan0 - count[0];
+                    for (uint32_t c = 0; c < count[0]; ++c) items[at + c] = static_cast<uint16_t>(lane | (c << 7));
+                    at = total0 + scan1 - count[1];
+                    for (uint32_t c = 0; c < count[1]; ++c)
+                        items[at + c] = static_cast<uint16_t>((lane + 64) | (c << 7));
+                }
+                if (lane == 0) {
+                    ctrl[kLItems] = static_cast<int32_t>(n_items);
+                    ctrl[kLQuads] = static_cast<int32_t>(quads_here);
                 }
             }
             __syncthreads();
-            DS_STAMP(2);
-            // (2) scan (and re-zero) the tile
-            const int64_t tile_base = static_cast<int64_t>(b) << kTileLog2;
-            const int64_t rows_left = a.n_truth - tile_base;
-            const int limit = rows_left >= kTile ? kTile : static_cast<int>((rows_left + 3) & ~int64_t(3));
-            int r0 = 0;
-            while (r0 < limit) {
-                const int r1 = tight ? limit : min(r0 + kLooseStep, limit);
-                for (int idx = r0 + tid * 4; idx < r1; idx += kThreads * 4) {
-                    const float4 s4 = *reinterpret_cast<float4 *>(&scores[idx]);
-                    *reinterpret_cast<float4 *>(&scores[idx]) = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const bool any = s4.x >= pre || s4.y >= pre || s4.z >= pre || s4.w >= pre;
-                    if (__ballot(any) == 0) continue;
-                    const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+            const int n_items = ctrl[kLItems];
+            if (n_items > kMaxItems) { slow = true; reason = 1; break; }
+            const bool sparse = tight && ctrl[kLQuads] <= a.sparse_quads;
+            DS_STAMP(1);
+
+            // ---- (1) scatter: fixed-point LDS atomics (ds_add_u32); padding entries hit the trash slot scores[kTile].
+            // A wave owns whole items; two items (up to 8 quad loads per lane) are in flight at a time.  When the
+            // whole tile is a single batch the quads stay in registers for the exchange sweep.
+            const bool single_batch = n_items <= 2 * kWaves;
+            uint2 quad[8], quad_sums[8];
+            bool live[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float s = sv[e];
-                        const int64_t t = tile_base + idx + e;
-                        bool pass = s >= pre;
-                        uint32_t key = 0;
-                        if (pass) {
-                            const float sums = a.sums32[t];
-                            pass = s >= coef * (sums + maxint32);
-                            if (pass) {
-                                const float denominator = sums + (maxint32 - s);
-                                const float approx = s / denominator;
-                                key = (denominator > 0.f && approx == approx) ? __float_as_uint(approx) : 0x7f800000u;
-                            }
-                        }
-                        const unsigned long long votes = __ballot(pass);
-                        if (votes != 0) {
-                            const int leader = __ffsll(votes) - 1;
-                            int base = 0;
-                            if (lane == leader) base = atomicAdd(const_cast<int32_t *>(&ctrl[kLCount]), __popcll(votes));
-                            base = __shfl(base, leader);
-                            if (pass) {
-                                const int slot = base + __popcll(votes & ((1ull << lane) - 1ull));
-                                if (slot < kCandidates) {
-                                    cand_key[slot] = key;
-                                    cand_row[slot] = static_cast<int32_t>(t);
-                                } else {
-                                    ctrl[kLOverflow] = 1;
-                                }
+            for (int u = 0; u < 8; ++u) live[u] = false;
+            for (int it = wave; it < n_items; it += 2 * kWaves) {
+                uint32_t value[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int at = it + h * kWaves;
+                    const bool item_ok = at < n_items;
+                    const uint32_t item = item_ok ? items[at] : 0u;
+                    const int j = item & 127u;
+                    const uint32_t first = list_begin[j] + (item >> 7) * kItemQuads + lane;
+                    const uint32_t end = item_ok ? list_end[j] : 0u;
+                    value[h] = fixed[j];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t index = first + u * 64;
+                        live[h * 4 + u] = index < end;
+                        quad[h * 4 + u] = live[h * 4 + u] ? quads[index] : make_uint2(0x80008000u, 0x80008000u);
+                        if (sparse && single_batch && live[h * 4 + u]) quad_sums[h * 4 + u] = sums_quads[index];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (!live[u]) continue;
+                    const uint32_t v = value[u >> 2];
+                    atomicAdd(&iscores[quad[u].x & 0xffffu], v);
+                    atomicAdd(&iscores[quad[u].x >> 16], v);
+                    atomicAdd(&iscores[quad[u].y & 0xffffu], v);
+                    atomicAdd(&iscores[quad[u].y >> 16], v);
+                }
+            }
+            __syncthreads();
+            DS_STAMP(sparse ? 6 : 2);
+
+            const int64_t tile_base = static_cast<int64_t>(b) << kTileLog2;
+            // row-independent gate of this tile: coef * (min sums of the tile + maxint), rounded down
+            Bounds here = bounds;
+            {
+                const float gate = bounds.coef * (a.tile_sums_min[b] + maxint32) * (1.f - 3.814697265625e-06f);
+                if (gate > here.pre) here.pre = gate;
+            }
+            // A sweep only runs the register-level tests and appends RAW entries (approximate essential score, row);
+            // `refine` then turns the raw entries of the sweep into candidates (exact sums, completion of the skipped
+            // columns, tight test) with one thread per entry, or drops them.
+            auto consider = [&](float s, uint32_t local, bool have_bound, float sums_lower_bound) {
+                bool pass = s > 0.f && s + here.mass >= here.pre;
+                // sparse sweep: the posting carries a bfloat16 lower bound of sums[t] (no gather)
+                if (have_bound) pass = pass && may_qualify(s, sums_lower_bound, here);
+                append_candidate(pass, __float_as_uint(s), static_cast<int32_t>(tile_base + local), cand_key,
+                                 cand_row, ctrl, lane);
+            };
+            auto refine = [&](int first_raw) {  // called by all threads after a barrier; ends with a barrier
+                const int last_raw = min(static_cast<int>(ctrl[kLCount]), kCandidates);
+                if (last_raw <= first_raw) return;
+                if (tid == 0 && a.phase != nullptr) {
+                    atomicAdd(&a.control[kCtlRefines], 1);
+                    atomicAdd(&a.control[kCtlRawEntries], last_raw - first_raw);
+                    if (skipped.without_bit > 0) atomicAdd(&a.control[kCtlSearches], 1);
+                }
+                uint32_t keep_key[kKeep];
+                int32_t keep_row[kKeep];
+#pragma unroll
+                for (int r = 0; r < kKeep; ++r) {
+                    const int i = first_raw + tid + r * kThreads;
+                    keep_row[r] = -1;
+                    keep_key[r] = 0u;
+                    if (i < last_raw) {
+                        const int32_t t = cand_row[i];
+                        const float raw = __uint_as_float(cand_key[i]);
+                        const float sums = a.sums32[t];
+                        const uint4 signature = skipped.count > 0 ? a.signature[t] : make_uint4(0u, 0u, 0u, 0u);
+                        if (may_qualify(raw, sums, here)) {
+                            const float full =
+                                complete_score(raw, signature, static_cast<uint32_t>(t - tile_base), skipped, bt, order,
+                                               sig_bit, bit_idf, ptr_cache, idf, a.postings);
+                            uint32_t key = 0;
+                            if (candidate_key(full, sums, here, key)) {
+                                keep_key[r] = key;
+                                keep_row[r] = t;
                             }
                         }
                     }
                 }
                 __syncthreads();
-                DS_STAMP(3);
-                r0 = r1;
-                if (ctrl[kLOverflow]) { slow = true; break; }
-                const int m = ctrl[kLCount];
-                if (m >= next_select) {
-                    // tighten: tau = k-th largest approximate jaccard seen so far; keep what can still qualify
-                    const uint32_t tau_key = radix_select_kth(cand_key, m, k, hist, ctrl);
-                    ++selects;
-                    if (tid == 0) {
-                        const double tau = static_cast<double>(__uint_as_float(tau_key));
-                        const double cut_value = tau - 2.0 * margin - 2e-6;
-                        float new_coef = 0.f, new_pre = FLT_MIN, new_cut = 0.f;
-                        if (tau_key < 0x7f800000u && cut_value > 0.0) {
-                            const double c = cut_value / (1.0 + cut_value) * (1.0 - 9.5367431640625e-07);
-                            new_coef = round_down_positive(c);
-                            new_cut = round_down_positive(cut_value);
-                            const double p = static_cast<double>(new_coef) *
-                                             (static_cast<double>(a.sums_min) + static_cast<double>(maxint32)) *
-                                             (1.0 - 9.5367431640625e-07);
-                            new_pre = p > static_cast<double>(FLT_MIN) ? round_down_positive(p) : FLT_MIN;
+                if (tid == 0) ctrl[kLCount] = first_raw;
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < kKeep; ++r) {
+                    if (keep_row[r] >= 0) {
+                        const int slot = atomicAdd(const_cast<int32_t *>(&ctrl[kLCount]), 1);
+                        cand_key[slot] = keep_key[r];
+                        cand_row[slot] = keep_row[r];
+                    }
+                }
+                __syncthreads();
+            };
+            int first_raw = ctrl[kLCount];
+            if (sparse) {
+                // ---- (2s) exchange sweep over the same postings: the first lane to reach a row takes its score and
+                // leaves zero behind; rows that can still qualify become candidates
+                ++sparse_tiles;
+                for (int it = wave; it < n_items; it += 2 * kWaves) {
+                    if (!single_batch) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int at = it + h * kWaves;
+                            const bool item_ok = at < n_items;
+                            const uint32_t item = item_ok ? items[at] : 0u;
+                            const int j = item & 127u;
+                            const uint32_t first = list_begin[j] + (item >> 7) * kItemQuads + lane;
+                            const uint32_t end = item_ok ? list_end[j] : 0u;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const uint32_t index = first + u * 64;
+                                live[h * 4 + u] = index < end;
+                                quad[h * 4 + u] =
+                                    live[h * 4 + u] ? quads[index] : make_uint2(0x80008000u, 0x80008000u);
+                                if (live[h * 4 + u]) quad_sums[h * 4 + u] = sums_quads[index];
+                            }
                         }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (__ballot(live[u]) == 0) continue;
+                        const uint32_t local[4] = {quad[u].x & 0xffffu, quad[u].x >> 16, quad[u].y & 0xffffu,
+                                                   quad[u].y >> 16};
+                        const float bound[4] = {__uint_as_float(quad_sums[u].x << 16),
+                                                __uint_as_float(quad_sums[u].x & 0xffff0000u),
+                                                __uint_as_float(quad_sums[u].y << 16),
+                                                __uint_as_float(quad_sums[u].y & 0xffff0000u)};
+                        uint32_t taken[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            taken[e] = (live[u] && local[e] < kTile) ? atomicExch(&iscores[local[e]], 0u) : 0u;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            consider(static_cast<float>(taken[e]) * from_fixed, local[e], true, bound[e]);
+                    }
+                }
+                __syncthreads();
+                if (ctrl[kLOverflow]) { slow = true; reason = 2; break; }
+                refine(first_raw);
+                first_raw = ctrl[kLCount];
+                DS_STAMP(7);
+            }
+
+            // ---- (2d) dense scan (and re-zero) of the tile; in steps while no running value exists
+            const int64_t rows_left = a.n_truth - tile_base;
+            const int limit = rows_left >= kTile ? kTile : static_cast<int>((rows_left + 3) & ~int64_t(3));
+            int r0 = sparse ? limit : 0;
+            if (!sparse) ++dense_tiles;
+            bool select_now = sparse && ctrl[kLCount] >= next_select;
+            while (r0 < limit || select_now) {
+                if (r0 < limit) {
+                    const int r1 = tight ? limit : min(r0 + kLooseStep, limit);
+                    for (int idx = r0 + tid * 4; idx < r1; idx += kThreads * 4) {
+                        const uint4 raw4 = *reinterpret_cast<uint4 *>(&iscores[idx]);
+                        *reinterpret_cast<uint4 *>(&iscores[idx]) = make_uint4(0u, 0u, 0u, 0u);
+                        const float4 s4 = make_float4(static_cast<float>(raw4.x) * from_fixed,
+                                                      static_cast<float>(raw4.y) * from_fixed,
+                                                      static_cast<float>(raw4.z) * from_fixed,
+                                                      static_cast<float>(raw4.w) * from_fixed);
+                        // mass < pre by construction, so untouched rows (score 0) never pass
+                        const bool any = s4.x + here.mass >= here.pre || s4.y + here.mass >= here.pre ||
+                                         s4.z + here.mass >= here.pre || s4.w + here.mass >= here.pre;
+                        if (__ballot(any) == 0) continue;
+                        // sums of the four rows in one coalesced load (the array is padded by four entries)
+                        const float4 sums4 = *reinterpret_cast<const float4 *>(&a.sums32[tile_base + idx]);
+                        consider(s4.x, static_cast<uint32_t>(idx), true, sums4.x);
+                        consider(s4.y, static_cast<uint32_t>(idx + 1), true, sums4.y);
+                        consider(s4.z, static_cast<uint32_t>(idx + 2), true, sums4.z);
+                        consider(s4.w, static_cast<uint32_t>(idx + 3), true, sums4.w);
+                    }
+                    __syncthreads();
+                    r0 = r1;
+                    if (ctrl[kLOverflow]) { slow = true; reason = 3; break; }
+                    refine(first_raw);
+                    first_raw = ctrl[kLCount];
+                    DS_STAMP(3);
+                }
+                select_now = false;
+                const int m = ctrl[kLCount];
+                if (m < next_select) continue;
+                // ---- tighten: tau = k-th largest lower estimate seen so far; keep what can still qualify
+                const uint32_t tau_key = radix_select_kth(cand_key, m, k, hist, ctrl);
+                ++selects;
+                if (wave == 0) {
+                    const double tau = static_cast<double>(__uint_as_float(tau_key));
+                    const double cut_value = tau - 2.0 * margin - 2e-6;
+                    float new_coef = 0.f, new_pre = FLT_MIN, new_cut = 0.f;
+                    if (tau_key < 0x7f800000u && cut_value > 0.0) {
+                        const double c = cut_value / (1.0 + cut_value) * (1.0 - 9.5367431640625e-07);
+                        new_coef = round_down_positive(c);
+                        new_cut = round_down_positive(cut_value);
+                        const double p = static_cast<double>(new_coef) *
+                                         (static_cast<double>(a.sums_min) + static_cast<double>(maxint32)) *
+                                         (1.0 - 9.5367431640625e-07);
+                        new_pre = p > static_cast<double>(FLT_MIN) ? round_down_positive(p) : FLT_MIN;
+                    }
+                    // non-essential columns: the longest ascending-IDF prefix whose total mass stays below `pre`
+                    int skip_count = 0;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int r = lane + 64 * h;
+                        skip_count += __popcll(__ballot(r < n && mass_upto[r] < new_pre));
+                    }
+                    uint32_t mask_bits[kSignatureWords] = {0u, 0u, 0u, 0u};
+                    int without_bit = 0;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int r = lane + 64 * h;
+                        const int bit = r < skip_count ? sig_bit[order[r]] : 0;
+                        if (r < skip_count && bit >= 0) {
+#pragma unroll
+                            for (int w = 0; w < kSignatureWords; ++w)
+                                if ((bit >> 5) == w) mask_bits[w] |= 1u << (bit & 31);
+                        }
+                        without_bit += __popcll(__ballot(r < skip_count && bit < 0));
+                    }
+#pragma unroll
+                    for (int w = 0; w < kSignatureWords; ++w)
+                        for (int d = 32; d > 0; d >>= 1) mask_bits[w] |= __shfl_xor(mask_bits[w], d);
+                    if (lane == 0) {
+                        for (int w = 0; w < kSignatureWords; ++w) ctrl[kLSigMask + w] = static_cast<int32_t>(mask_bits[w]);
+                        ctrl[kLUnsigned] = without_bit;
                         ctrl[kLCoef] = __float_as_int(new_coef);
                         ctrl[kLPre] = __float_as_int(new_pre);
                         ctrl[kLCut] = __float_as_int(new_cut);
+                        ctrl[kLNonEssential] = skip_count;
+                        ctrl[kLMass] = __float_as_int(skip_count > 0 ? mass_upto[skip_count - 1] : 0.f);
                     }
-                    __syncthreads();
-                    coef = __int_as_float(ctrl[kLCoef]);
-                    pre = __int_as_float(ctrl[kLPre]);
-                    cut = __int_as_float(ctrl[kLCut]);
-                    tight = true;
-                    // in-place compaction: read everything, barrier, rewrite the survivors
-                    uint32_t keep_key[kCandidates / kThreads];
-                    int32_t keep_row[kCandidates / kThreads];
-#pragma unroll
-                    for (int r = 0; r < kCandidates / kThreads; ++r) {
-                        const int i = tid + r * kThreads;
-                        keep_key[r] = i < m ? cand_key[i] : 0u;
-                        keep_row[r] = i < m ? cand_row[i] : -1;
-                    }
-                    __syncthreads();
-                    if (tid == 0) ctrl[kLCount] = 0;
-                    __syncthreads();
-#pragma unroll
-                    for (int r = 0; r < kCandidates / kThreads; ++r) {
-                        if (keep_row[r] >= 0 && __uint_as_float(keep_key[r]) >= cut) {
-                            const int slot = atomicAdd(const_cast<int32_t *>(&ctrl[kLCount]), 1);
-                            cand_key[slot] = keep_key[r];
-                            cand_row[slot] = keep_row[r];
-                        }
-                    }
-                    __syncthreads();
-                    const int kept = ctrl[kLCount];
-                    if (kept > kSelectTrigger) { slow = true; break; }  // massive ties: use the dense kernel
-                    next_select = min(kSelectTrigger, max(2 * kept, max(4 * k, 64)));
-                    DS_STAMP(4);
                 }
-            }
-        }
-
-        int m = slow ? 0 : ctrl[kLCount];
-        if (!slow && m < k) slow = true;  // fewer than k positive rows (never tightened): literal path decides
-        if (!slow) {
-            // final tightening so that only k + near-ties + margin survivors are evaluated exactly
-            if (m > k) {
-                const uint32_t tau_key = radix_select_kth(cand_key, m, k, hist, ctrl);
-                ++selects;
-                const double tau = static_cast<double>(__uint_as_float(tau_key));
-                const double cut_value = tau - 2.0 * margin - 2e-6;
-                const float final_cut = (tau_key < 0x7f800000u && cut_value > 0.0) ? round_down_positive(cut_value) : 0.f;
-                uint32_t keep_key[kCandidates / kThreads];
-                int32_t keep_row[kCandidates / kThreads];
+                __syncthreads();
+                bounds.coef = __int_as_float(ctrl[kLCoef]);
+                bounds.pre = __int_as_float(ctrl[kLPre]);
+                here.coef = bounds.coef;
+                {
+                    const float gate = bounds.coef * (a.tile_sums_min[b] + maxint32) * (1.f - 3.814697265625e-06f);
+                    here.pre = gate > bounds.pre ? gate : bounds.pre;
+                }
+                pending_mass = __int_as_float(ctrl[kLMass]);
+                for (int w = 0; w < kSignatureWords; ++w) pending_sig_mask[w] = static_cast<uint32_t>(ctrl[kLSigMask + w]);
+                pending_without_bit = ctrl[kLUnsigned];
+                cut = __int_as_float(ctrl[kLCut]);
+                non_essential = ctrl[kLNonEssential];
+                tight = true;
+                // in-place compaction: read everything, barrier, rewrite the survivors
+                uint32_t keep_key[kKeep];
+                int32_t keep_row[kKeep];
 #pragma unroll
-                for (int r = 0; r < kCandidates / kThreads; ++r) {
+                for (int r = 0; r < kKeep; ++r) {
                     const int i = tid + r * kThreads;
                     keep_key[r] = i < m ? cand_key[i] : 0u;
                     keep_row[r] = i < m ? cand_row[i] : -1;
@@ -347,7 +680,46 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                 if (tid == 0) ctrl[kLCount] = 0;
                 __syncthreads();
 #pragma unroll
-                for (int r = 0; r < kCandidates / kThreads; ++r) {
+                for (int r = 0; r < kKeep; ++r) {
+                    if (keep_row[r] >= 0 && __uint_as_float(keep_key[r]) >= cut) {
+                        const int slot = atomicAdd(const_cast<int32_t *>(&ctrl[kLCount]), 1);
+                        cand_key[slot] = keep_key[r];
+                        cand_row[slot] = keep_row[r];
+                    }
+                }
+                __syncthreads();
+                const int kept = ctrl[kLCount];
+                if (kept > kSelectTrigger) { slow = true; reason = 4; break; }  // massive ties: use the dense kernel
+                next_select = min(kSelectTrigger, max(2 * kept, max(4 * k, 64)));
+                first_raw = kept;
+                DS_STAMP(4);
+            }
+        }
+
+        int m = slow ? 0 : ctrl[kLCount];
+        if (!slow && m < k) { slow = true; reason = 5; }  // fewer than k positive rows: literal path decides
+        if (!slow) {
+            // final tightening so that only k + near-ties + margin survivors are evaluated exactly
+            if (m > k) {
+                const uint32_t tau_key = radix_select_kth(cand_key, m, k, hist, ctrl);
+                ++selects;
+                const double tau = static_cast<double>(__uint_as_float(tau_key));
+                const double cut_value = tau - 2.0 * margin - 2e-6;
+                const float final_cut =
+                    (tau_key < 0x7f800000u && cut_value > 0.0) ? round_down_positive(cut_value) : 0.f;
+                uint32_t keep_key[kKeep];
+                int32_t keep_row[kKeep];
+#pragma unroll
+                for (int r = 0; r < kKeep; ++r) {
+                    const int i = tid + r * kThreads;
+                    keep_key[r] = i < m ? cand_key[i] : 0u;
+                    keep_row[r] = i < m ? cand_row[i] : -1;
+                }
+                __syncthreads();
+                if (tid == 0) ctrl[kLCount] = 0;
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < kKeep; ++r) {
                     if (keep_row[r] >= 0 && __uint_as_float(keep_key[r]) >= final_cut) {
                         const int slot = atomicAdd(const_cast<int32_t *>(&ctrl[kLCount]), 1);
                         cand_row[slot] = keep_row[r];
@@ -356,77 +728,89 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                 __syncthreads();
                 m = ctrl[kLCount];
             }
-            // exact evaluation, one wave per candidate; results live in the (all-zero) score tile
-            double *exact_jaccard = reinterpret_cast<double *>(scores);
-            int32_t *exact_row = reinterpret_cast<int32_t *>(scores + 2 * kCandidates);
-            for (int i = wave; i < m; i += kThreads / 64) {
+            DS_STAMP(4);
+            // ---- exact evaluation.  Scratch lives in the (all-zero) score tile:
+            //   hit masks   uint32[m][4]  (bit j = row is in the posting list of query column j)
+            //   exact value float64[m]    at byte offset 32768
+            uint32_t *hit_mask = reinterpret_cast<uint32_t *>(scores);
+            double *exact_jaccard = reinterpret_cast<double *>(lds + 32768);
+            for (int p = tid; p < m * n; p += kThreads) {  // one (candidate, column) membership test per thread
+                const int i = p / n, j = p - i * n;
                 const int32_t t = cand_row[i];
-                const int32_t tile = t >> kTileLog2;
-                const uint32_t local = static_cast<uint32_t>(t & (kTile - 1));
-                const uint32_t *ptr_row = a.tile_ptr + static_cast<int64_t>(tile) * ptr_stride;
+                bool hit;
+                if (sig_bit[j] >= 0) {
+                    const uint32_t *words = reinterpret_cast<const uint32_t *>(a.signature + t);
+                    hit = (words[sig_bit[j] >> 5] >> (sig_bit[j] & 31)) & 1u;  // exact membership bit of a dense column
+                } else {
+                    const int32_t tile = t >> kTileLog2;
+                    const uint32_t local = static_cast<uint32_t>(t & (kTile - 1));
+                    const uint32_t *ptr = a.col_ptr + static_cast<int64_t>(cols[j]) * ptr_stride + tile;
+                    uint32_t lo = ptr[0] * 4u;
+                    const uint32_t end = ptr[1] * 4u;
+                    uint32_t hi = end;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (a.postings[mid] < local) lo = mid + 1; else hi = mid;
+                    }
+                    hit = lo < end && a.postings[lo] == local;
+                }
+                if (hit) atomicOr(&hit_mask[i * 4 + (j >> 5)], 1u << (j & 31));
+            }
+            __syncthreads();
+            for (int i = tid; i < m; i += kThreads) {
                 float score = 0.f;
-                for (int c0 = 0; c0 < n; c0 += 64) {
-                    const int j = c0 + lane;
-                    bool hit = false;
-                    if (j < n) {
-                        uint32_t lo = ptr_row[cols[j]] * 4u;
-                        const uint32_t end = ptr_row[cols[j] + 1] * 4u;
-                        uint32_t hi = end;
-                        while (lo < hi) {
-                            const uint32_t mid = (lo + hi) >> 1;
-                            if (a.postings[mid] < local) lo = mid + 1; else hi = mid;
-                        }
-                        hit = lo < end && a.postings[lo] == local;
-                    }
-                    unsigned long long hits = __ballot(hit);
-                    while (hits) {  // float32 accumulation in the query's column order (match_maker.py:46-48)
-                        const int jj = __ffsll(hits) - 1;
-                        score = score + idf[c0 + jj];
-                        hits &= hits - 1ull;
+                for (int word = 0; word < 4; ++word) {
+                    uint32_t bits = hit_mask[i * 4 + word];
+                    while (bits) {  // float32 accumulation in the query's column order (match_maker.py:46-48)
+                        const int j = word * 32 + __ffs(bits) - 1;
+                        score = score + idf[j];
+                        bits &= bits - 1u;
                     }
                 }
-                if (lane == 0) {
-                    const double s = static_cast<double>(score);
-                    exact_jaccard[i] = s / (static_cast<double>(a.sums32[t]) + (maxint - s));  // match_maker.py:50
-                    exact_row[i] = t;
-                }
+                const double s = static_cast<double>(score);
+                exact_jaccard[i] = s / (static_cast<double>(a.sums32[cand_row[i]]) + (maxint - s));  // :50
             }
             __syncthreads();
             // k-th largest exact value (rank by counting; m is small)
             for (int i = tid; i < m; i += kThreads) {
                 const double v = exact_jaccard[i];
-                int rank = 0;
+                int above = 0;
                 for (int j = 0; j < m; ++j) {
                     const double w = exact_jaccard[j];
-                    rank += (w > v) || (w == v && j < i);
+                    above += (w > v) || (w == v && j < i);
                 }
-                if (rank == k - 1) {
+                if (above == k - 1) {
                     ctrl[kLKth0] = __double2loint(v);
                     ctrl[kLKth1] = __double2hiint(v);
                 }
             }
             __syncthreads();
             const double kth = __hiloint2double(ctrl[kLKth1], ctrl[kLKth0]);
-            const float kth32 = static_cast<float>(kth);                                   // match_maker.py:65
+            const float kth32 = static_cast<float>(kth);                                       // match_maker.py:65
             const double threshold = static_cast<double>(kth32) - static_cast<double>(1e-6f);  // match_maker.py:70
             if (threshold <= 0.0) {
                 // every row qualifies (zeros included): the k largest row indexes
-                for (int j = tid; j < k; j += kThreads) a.out_rows[q * k + j] = static_cast<int32_t>(a.n_truth - 1 - j);
+                for (int j = tid; j < k; j += kThreads)
+                    a.out_rows[q * k + j] = static_cast<int32_t>(a.n_truth - 1 - j);
             } else {
                 for (int i = tid; i < m; i += kThreads) {
-                    if (!(exact_jaccard[i] >= threshold)) continue;                          // match_maker.py:71
-                    const int32_t t = exact_row[i];
+                    if (!(exact_jaccard[i] >= threshold)) continue;                            // match_maker.py:71
+                    const int32_t t = cand_row[i];
                     int above = 0;
-                    for (int j = 0; j < m; ++j) above += (exact_jaccard[j] >= threshold) && exact_row[j] > t;
+                    for (int j = 0; j < m; ++j) above += (exact_jaccard[j] >= threshold) && cand_row[j] > t;
                     if (above < k) a.out_rows[q * k + above] = t;
                 }
             }
             __syncthreads();
-            for (int i = tid; i < 3 * kCandidates; i += kThreads) scores[i] = 0.f;  // give the tile back zeroed
+            for (int i = tid; i < m * 4; i += kThreads) hit_mask[i] = 0u;  // give the tile back zeroed
+            for (int i = tid; i < m; i += kThreads) exact_jaccard[i] = 0.0;
             if (tid == 0) {
                 a.status[q] = kQueryDone;
                 atomicAdd(&a.control[kCtlExact], m);
                 atomicAdd(&a.control[kCtlSelects], selects);
+                atomicAdd(&a.control[kCtlSparseTiles], sparse_tiles);
+                atomicAdd(&a.control[kCtlDenseTiles], dense_tiles);
+                atomicAdd(&a.control[kCtlSkippedColumns], non_essential);
             }
             __syncthreads();
             DS_STAMP(5);
@@ -434,11 +818,12 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             if (tid == 0) {
                 a.status[q] = kQuerySlow;
                 a.slow_list[atomicAdd(&a.control[kCtlSlowCount], 1)] = static_cast<int32_t>(q);
+                if (reason >= 0) atomicAdd(&a.control[kCtlReason + reason], 1);
             }
             for (int i = tid * 4; i < kScoreFloats; i += kThreads * 4)
                 *reinterpret_cast<float4 *>(&scores[i]) = make_float4(0.f, 0.f, 0.f, 0.f);
             __syncthreads();
-            DS_STAMP(6);
+            DS_STAMP(0);
         }
     }
 }
@@ -457,7 +842,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_dense_kernel(JaccardArgs 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.k;
     const int64_t n_truth = a.n_truth;
-    const int64_t ptr_stride = a.n_columns + 1;
+    const int64_t ptr_stride = static_cast<int64_t>(a.n_tiles) + 1;
     double *jaccard = a.slow_scratch + static_cast<int64_t>(blockIdx.x) * n_truth;
     const int n_slow = a.control[kCtlSlowCount];
 
@@ -490,11 +875,11 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_dense_kernel(JaccardArgs 
         for (int b = 0; b < a.n_tiles; ++b) {
             for (int i = tid; i < kScoreFloats; i += kThreads) scores[i] = 0.f;
             __syncthreads();
-            const uint32_t *ptr_row = a.tile_ptr + static_cast<int64_t>(b) * ptr_stride;
             for (int64_t j = 0; j < n; ++j) {
                 const int32_t column = a.q_cols[qbase + j];
                 const float value = a.idf32[column];
-                const uint32_t begin = ptr_row[column] * 4u, end = ptr_row[column + 1] * 4u;
+                const uint32_t *ptr = a.col_ptr + static_cast<int64_t>(column) * ptr_stride + b;
+                const uint32_t begin = ptr[0] * 4u, end = ptr[1] * 4u;
                 for (uint32_t i = begin + tid; i < end; i += kThreads) {
                     const uint32_t local = a.postings[i];
                     if (local < kTile) scores[local] = scores[local] + value;  // each row at most once per list
@@ -596,19 +981,22 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
         if (status == DS_OK) status = index->slow_list.allocate(static_cast<size_t>(Q));
         if (status != DS_OK) return status;
     }
-    static bool attributes_set = false;
-    if (!attributes_set) {
+    if (!index->attributes_set) {
         DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ds_jaccard_topk_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kFastLdsBytes));
         DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ds_jaccard_dense_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kDenseLdsBytes));
-        attributes_set = true;
+        index->attributes_set = true;
     }
     JaccardArgs args;
-    args.tile_ptr = index->tile_ptr.ptr;
+    args.col_ptr = index->col_ptr.ptr;
     args.postings = index->postings.ptr;
+    args.posting_sums = index->posting_sums.ptr;
     args.idf32 = index->idf32.ptr;
     args.sums32 = index->sums32.ptr;
+    args.tile_sums_min = index->tile_sums_min.ptr;
+    args.signature = reinterpret_cast<const uint4 *>(index->signature.ptr);
+    args.sig_column = index->sig_column.ptr;
     args.q_rowptr = d_q_rowptr;
     args.q_cols = d_q_cols;
     args.q_maxint = d_q_maxint;
@@ -628,13 +1016,12 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     args.n_queries = Q;
     args.n_tiles = static_cast<int32_t>(index->n_tiles);
     args.k = k;
+    args.sparse_quads = 4096;
+    if (const char *limit = getenv("DS_SPARSE_QUADS"); limit != nullptr) args.sparse_quads = atoi(limit);
     args.sums_min = index->sums_min;
 
-    hipDeviceProp_t properties;
-    DS_HIP(hipGetDeviceProperties(&properties, index->device));
-    const int64_t cus = properties.multiProcessorCount > 0 ? properties.multiProcessorCount : 256;
-    const int grid = static_cast<int>(std::min<int64_t>(Q, cus));
-    DS_HIP(hipMemsetAsync(index->control.ptr, 0, 16 * sizeof(int32_t), stream));
+    const int grid = static_cast<int>(std::min<int64_t>(Q, index->compute_units));
+    DS_HIP(hipMemsetAsync(index->control.ptr, 0, kControlWords * sizeof(int32_t), stream));
     hipLaunchKernelGGL(ds_jaccard_topk_kernel, dim3(grid), dim3(kThreads), kFastLdsBytes, stream, args);
     DS_HIP(hipGetLastError());
     hipLaunchKernelGGL(ds_jaccard_dense_kernel, dim3(kSlowSlots), dim3(kThreads), kDenseLdsBytes, stream, args);
@@ -642,11 +1029,11 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     return DS_OK;
 }
 
-static int collect(ds_index *index, hipStream_t stream, int64_t stats[16])
+static int collect(ds_index *index, hipStream_t stream, int64_t stats[32])
 {
     DS_REQUIRE(index != nullptr, "ds_jaccard_sync: null index");
     DS_HIP(hipSetDevice(index->device));
-    int32_t control[16] = {0};
+    int32_t control[kControlWords] = {0};
     DS_HIP(hipMemcpyAsync(control, index->control.ptr, sizeof(control), hipMemcpyDeviceToHost, stream));
     DS_HIP(hipStreamSynchronize(stream));
     if (stats) {
@@ -660,6 +1047,15 @@ static int collect(ds_index *index, hipStream_t stream, int64_t stats[16])
             DS_HIP(hipMemcpy(phase, index->phase.ptr, sizeof(phase), hipMemcpyDeviceToHost));
             for (int i = 0; i < 8; ++i) stats[4 + i] = static_cast<int64_t>(phase[i]);
         }
+        stats[12] = control[kCtlSparseTiles];
+        stats[13] = control[kCtlDenseTiles];
+        stats[14] = control[kCtlSkippedColumns];
+        stats[15] = 0;
+        for (int i = 0; i < 6; ++i) stats[16 + i] = control[kCtlReason + i];
+        stats[22] = control[kCtlRefines];
+        stats[23] = control[kCtlRawEntries];
+        stats[24] = control[kCtlSearches];
+        for (int i = 25; i < 32; ++i) stats[i] = 0;
     }
     if (control[kCtlErrors] != 0 && index->last_queries > 0) {
         std::vector<int32_t> status(static_cast<size_t>(index->last_queries));
@@ -688,7 +1084,7 @@ int ds_jaccard_topk_device(ds_index *index, const int64_t *d_q_rowptr, const int
     return ds::launch(index, d_q_rowptr, d_q_cols, d_q_maxint, Q, k, d_out_rows, static_cast<hipStream_t>(stream));
 }
 
-int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[16])
+int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[32])
 {
     return ds::collect(index, static_cast<hipStream_t>(stream), stats);
 }

@@ -52,9 +52,10 @@ int ds_device_name(int device, char *name, size_t capacity)
 
 // ---- tiled index ---------------------------------------------------------------------------------------------------
 // Input: the V x N inverted index of match_maker.py:122-133 in CSR form.  Output (HBM): the truth rows are cut
-// into tiles of kTile rows; for every (tile, column) the posting sub-list is stored as uint16 tile-local rows,
-// padded to a multiple of four entries ("quad", one 8-byte load per lane) with kSentinel; tile_ptr[tile][column]
-// is the first quad of that sub-list.  The constant per-posting value of match_maker.py:130 is never stored.
+// into tiles of kTile rows; every column's posting list is stored tile after tile as uint16 tile-local rows, each
+// (column, tile) sub-list padded to a multiple of four entries ("quad", one 8-byte load per lane) with kSentinel;
+// col_ptr[column][tile] is the first quad of that sub-list, col_ptr[column][n_tiles] the end of the column.
+// The constant per-posting value of match_maker.py:130 is never stored.
 int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float *idf32, const float *sums32,
                     int64_t V, int64_t N, int device, ds_index **out)
 {
@@ -68,13 +69,15 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     const int64_t nnz = rowptr[V];
     DS_REQUIRE(nnz >= 0 && (nnz == 0 || truth_idx), "ds_index_create: bad nnz / truth_idx");
     const int64_t n_tiles = (N + ds::kTile - 1) / ds::kTile;
-    const int64_t row_stride = V + 1;
-    DS_REQUIRE(n_tiles * row_stride < (int64_t(1) << 40), "ds_index_create: tile pointer table too large");
+    const int64_t stride = n_tiles + 1;
+    DS_REQUIRE(V * stride < (int64_t(1) << 40), "ds_index_create: list pointer table too large");
 
-    // pass 1: quads per (tile, column), validating the posting lists
-    std::vector<uint32_t> tile_ptr(static_cast<size_t>(n_tiles * row_stride), 0u);
+    // pass 1: postings per (column, tile), validating the lists; then quads and offsets
+    std::vector<uint32_t> col_ptr(static_cast<size_t>(V * stride), 0u);
+    uint64_t quads = 0;
     for (int64_t g = 0; g < V; ++g) {
         DS_REQUIRE(rowptr[g + 1] >= rowptr[g], "ds_index_create: rowptr not monotone at column %lld", (long long)g);
+        uint32_t *row = col_ptr.data() + g * stride;
         int64_t previous = -1;
         for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
             const int64_t t = truth_idx[p];
@@ -82,56 +85,94 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
                        "ds_index_create: posting list of column %lld is not strictly ascending within [0, N)",
                        (long long)g);
             previous = t;
-            ++tile_ptr[static_cast<size_t>((t >> ds::kTileLog2) * row_stride + g)];
+            ++row[t >> ds::kTileLog2];
         }
-    }
-    uint64_t quads = 0;
-    for (int64_t b = 0; b < n_tiles; ++b) {
-        uint32_t *row = tile_ptr.data() + b * row_stride;
-        for (int64_t g = 0; g < V; ++g) {
-            const uint32_t count = row[g];
+        for (int64_t b = 0; b < n_tiles; ++b) {
+            const uint32_t count = row[b];
             DS_REQUIRE(quads < 0xfffffff0ull, "ds_index_create: more than 2^32 posting quads");
-            row[g] = static_cast<uint32_t>(quads);
+            row[b] = static_cast<uint32_t>(quads);
             quads += (count + 3u) / 4u;
         }
-        row[V] = static_cast<uint32_t>(quads);
+        row[n_tiles] = static_cast<uint32_t>(quads);
     }
     // pass 2: fill
     std::vector<uint16_t> postings(static_cast<size_t>(quads) * 4, static_cast<uint16_t>(ds::kSentinel));
-    {
-        std::vector<uint32_t> cursor(static_cast<size_t>(n_tiles), 0u);
-        for (int64_t g = 0; g < V; ++g) {
-            int64_t current_tile = -1;
-            uint64_t write = 0;
-            for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
-                const int64_t t = truth_idx[p];
-                const int64_t b = t >> ds::kTileLog2;
-                if (b != current_tile) {
-                    current_tile = b;
-                    write = static_cast<uint64_t>(tile_ptr[static_cast<size_t>(b * row_stride + g)]) * 4u;
-                }
-                postings[write++] = static_cast<uint16_t>(t & (ds::kTile - 1));
+    std::vector<uint16_t> posting_sums(static_cast<size_t>(quads) * 4, static_cast<uint16_t>(0x7f7f));
+    for (int64_t g = 0; g < V; ++g) {
+        const uint32_t *row = col_ptr.data() + g * stride;
+        int64_t current_tile = -1;
+        uint64_t write = 0;
+        for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
+            const int64_t t = truth_idx[p];
+            const int64_t b = t >> ds::kTileLog2;
+            if (b != current_tile) {
+                current_tile = b;
+                write = static_cast<uint64_t>(row[b]) * 4u;
             }
+            uint32_t sums_bits;
+            std::memcpy(&sums_bits, &sums32[t], sizeof(sums_bits));
+            posting_sums[write] = static_cast<uint16_t>(sums32[t] > 0.f ? sums_bits >> 16 : 0u);  // truncation: <= sums
+            postings[write++] = static_cast<uint16_t>(t & (ds::kTile - 1));
         }
     }
     float sums_min = sums32[0];
-    for (int64_t t = 1; t < N; ++t) sums_min = std::min(sums_min, sums32[t]);
+    std::vector<float> tile_sums_min(static_cast<size_t>(n_tiles), 0.f);
+    for (int64_t b = 0; b < n_tiles; ++b) {
+        const int64_t first = b << ds::kTileLog2, last = std::min<int64_t>(N, first + ds::kTile);
+        float lowest = sums32[first];
+        for (int64_t t = first + 1; t < last; ++t) lowest = std::min(lowest, sums32[t]);
+        tile_sums_min[static_cast<size_t>(b)] = lowest;
+        sums_min = std::min(sums_min, lowest);
+    }
+    // membership signature of the (up to) 128 densest columns: the columns a running threshold lets the kernel skip
+    // first are the lowest-IDF = longest lists; one 4-byte load then replaces a binary search per skipped column
+    std::vector<int8_t> sig_column(static_cast<size_t>(V), static_cast<int8_t>(-1));
+    std::vector<uint32_t> signature(static_cast<size_t>(N) * ds::kSignatureWords, 0u);
+    {
+        std::vector<int64_t> by_length(static_cast<size_t>(V));
+        for (int64_t g = 0; g < V; ++g) by_length[static_cast<size_t>(g)] = g;
+        const size_t top = static_cast<size_t>(std::min<int64_t>(V, ds::kSignatureBits));
+        std::partial_sort(by_length.begin(), by_length.begin() + top, by_length.end(), [&](int64_t x, int64_t y) {
+            const int64_t lx = rowptr[x + 1] - rowptr[x], ly = rowptr[y + 1] - rowptr[y];
+            return lx != ly ? lx > ly : x < y;
+        });
+        for (size_t bit = 0; bit < top; ++bit) {
+            const int64_t g = by_length[bit];
+            if ((rowptr[g + 1] - rowptr[g]) * 256 < N) break;  // not dense enough to be worth a bit
+            sig_column[static_cast<size_t>(g)] = static_cast<int8_t>(bit);
+            for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p)
+                signature[static_cast<size_t>(truth_idx[p]) * ds::kSignatureWords + (bit >> 5)] |= 1u << (bit & 31);
+        }
+    }
 
     DS_HIP(hipSetDevice(device));
+    hipDeviceProp_t properties;
+    DS_HIP(hipGetDeviceProperties(&properties, device));
     ds_index *index = new ds_index();
     index->device = device;
+    index->compute_units = properties.multiProcessorCount > 0 ? properties.multiProcessorCount : 256;
     index->n_truth = N;
     index->n_columns = V;
     index->nnz = nnz;
     index->n_tiles = n_tiles;
     index->n_quads = static_cast<int64_t>(quads);
     index->sums_min = sums_min;
-    int status = index->tile_ptr.upload(tile_ptr.data(), tile_ptr.size());
+    int status = index->col_ptr.upload(col_ptr.data(), col_ptr.size());
     if (status == DS_OK) status = index->postings.upload(postings.data(), postings.size());
+    if (status == DS_OK && postings.empty()) status = index->postings.allocate(4);
+    if (status == DS_OK) status = index->posting_sums.upload(posting_sums.data(), posting_sums.size());
+    if (status == DS_OK && posting_sums.empty()) status = index->posting_sums.allocate(4);
     if (status == DS_OK) status = index->idf32.upload(idf32, static_cast<size_t>(V));
-    if (status == DS_OK) status = index->sums32.upload(sums32, static_cast<size_t>(N));
+    if (status == DS_OK) {  // padded so that the dense scan may read four rows at once near the end
+        std::vector<float> padded(static_cast<size_t>(N) + 4, 0.f);
+        std::memcpy(padded.data(), sums32, sizeof(float) * static_cast<size_t>(N));
+        status = index->sums32.upload(padded.data(), padded.size());
+    }
+    if (status == DS_OK) status = index->tile_sums_min.upload(tile_sums_min.data(), tile_sums_min.size());
+    if (status == DS_OK) status = index->signature.upload(signature.data(), signature.size());
+    if (status == DS_OK) status = index->sig_column.upload(sig_column.data(), sig_column.size());
     if (status == DS_OK) status = index->slow_scratch.allocate(static_cast<size_t>(ds::kSlowSlots) * N);
-    if (status == DS_OK) status = index->control.allocate(16);
+    if (status == DS_OK) status = index->control.allocate(ds::kControlWords);
     if (status == DS_OK && hipStreamCreate(&index->stream) != hipSuccess) {
         ds::set_error("ds_index_create: hipStreamCreate failed");
         status = DS_E_HIP;
@@ -160,8 +201,9 @@ int ds_index_info(const ds_index *index, int64_t info[8])
     info[2] = index->nnz;
     info[3] = ds::kTile;
     info[4] = index->n_tiles;
-    info[5] = static_cast<int64_t>(index->tile_ptr.bytes() + index->postings.bytes() + index->idf32.bytes() +
-                                   index->sums32.bytes() + index->slow_scratch.bytes());
+    info[5] = static_cast<int64_t>(index->col_ptr.bytes() + index->postings.bytes() + index->posting_sums.bytes() + index->idf32.bytes() +
+                                   index->sums32.bytes() + index->signature.bytes() + index->sig_column.bytes() +
+                                   index->slow_scratch.bytes());
     info[6] = index->n_quads * 4;
     info[7] = 0;
     return DS_OK;

@@ -90,11 +90,16 @@ class TruthIndex:
             ctypes.c_void_p(stream or 0)), "ds_jaccard_topk_device")
 
     def sync(self, stream=None):
-        stats = (ctypes.c_int64 * 16)()
+        stats = (ctypes.c_int64 * 32)()
         _lib.check(_lib.lib().ds_jaccard_sync(self.handle, ctypes.c_void_p(stream or 0), stats), "ds_jaccard_sync")
-        names = ("setup", "list_pointers", "scatter", "scan", "select", "exact", "dense_handover")
+        names = ("setup", "list_pointers", "scatter_dense", "scan_dense", "select", "exact", "scatter_sparse",
+                 "collect_sparse")
         return {"dense_queries": stats[0], "error_queries": stats[1], "exact_candidates": stats[2],
-                "selections": stats[3], "phase_cycles": dict(zip(names, list(stats)[4:11]))}
+                "selections": stats[3], "phase_cycles": dict(zip(names, list(stats)[4:12])),
+                "sparse_tiles": stats[12], "dense_tiles": stats[13], "skipped_columns": stats[14],
+                "dense_reasons": dict(zip(("shape", "items", "overflow_sparse", "overflow_dense", "ties", "few"),
+                                          list(stats)[16:22])),
+                "refines": stats[22], "raw_entries": stats[23], "refines_with_search": stats[24]}
 
     def close(self):
         if self.handle:

@@ -71,8 +71,11 @@ int ds_jaccard_topk_device(ds_index *index, const int64_t *d_q_rowptr, const int
 /* Waits for `stream`, returns the status of the last ds_jaccard_topk_device on this index;
  * stats[0]=queries answered by the exact dense kernel, stats[1]=queries in error, stats[2]=candidates evaluated
  * exactly (total), stats[3]=threshold selections run (total), stats[4..11]=shader-clock sums per kernel phase
- * (setup, list pointers, scatter, scan, select, exact stage, dense hand-over; only with DS_PHASE_TIMERS=1). */
-int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[16]);
+ * (setup, list pointers, scatter, scan, select, exact stage, dense hand-over; only with DS_PHASE_TIMERS=1),
+ * stats[12]=tiles handled sparsely, stats[13]=tiles scanned densely, stats[14]=skipped (non-essential) columns
+ * summed over queries, stats[16..21]=queries handed to the dense kernel by reason (unsupported shape, work items,
+ * candidate overflow in a sparse tile, in a dense tile, ties after pruning, fewer than k positive rows). */
+int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[32]);
 
 /* ---- Levenshtein / features:  fast_levenshtein_ratio + construct_features (feature_engineering.py:25-169) ------- */
 /* The 9-argument gufunc of feature_engineering.py:69-80 without the `dummy` argument: rows of q_enc / t_enc are
