@@ -212,7 +212,7 @@ def main():
             "tiles": {"sparse": stats["sparse_tiles"], "dense": stats["dense_tiles"]},
             "skipped_columns_per_query": stats["skipped_columns"] / max(1, args.queries),
             "refine": {"calls": stats["refines"], "raw_entries": stats["raw_entries"],
-                       "with_binary_search": stats["refines_with_search"]},
+                       "survivors": stats["refine_survivors"], "raw_entries_sparse": stats["raw_entries_sparse"]},
             "roofline": {"bound": "hbm", "kernel": "ds_jaccard_topk_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_jaccard, "avg_launch_ms": mean_j},

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -17,7 +18,7 @@ namespace ds {
 constexpr int kTileLog2 = 15;
 constexpr int kTile = 1 << kTileLog2;        // truth rows per tile: one float32 score per row fills 128 KiB of LDS
 constexpr int kSentinel = kTile;             // padding entry of a posting quad: lands in the trash slot scores[kTile]
-constexpr int kThreads = 512;                // one 8-wave workgroup per CU (<= 256 VGPRs per lane)
+constexpr int kThreads = 1024;               // one 8-wave workgroup per CU (<= 256 VGPRs per lane)
 constexpr int kMaxQueryColumns = 128;        // fast-path limit (example data: p99 50, max 96 tri-grams per title)
 constexpr int kCandidates = 1792;            // capacity of the per-query candidate buffer in LDS
 constexpr int kLooseStep = 512;              // rows scanned between two capacity checks while no threshold exists
@@ -28,6 +29,18 @@ constexpr int kSignatureBits = 128;          // densest columns whose membership
 constexpr int kSignatureWords = kSignatureBits / 32;
 constexpr int kControlWords = 32;            // int32 control block in HBM (queue heads, counters)
 constexpr int kSlowSlots = 64;               // concurrent queries of the exact dense kernel (scratch = slots*N*8 B)
+
+// 8-bit lower bound of a positive float: 4 exponent bits (2^-3 .. 2^12) and 4 mantissa bits, truncated.
+// decode(encode(x)) <= x for every x >= 0; code 0 decodes to 0.
+inline uint32_t encode_sums8(float x)
+{
+    if (!(x >= 0.125f)) return 0u;
+    uint32_t bits;
+    memcpy(&bits, &x, sizeof(bits));
+    const int exponent = static_cast<int>(bits >> 23) - 124;  // 2^-3 -> 0
+    if (exponent > 15) return 0xffu;
+    return (static_cast<uint32_t>(exponent) << 4) | ((bits >> 19) & 0xfu);
+}
 
 enum QueryStatus : int32_t { kQueryDone = 0, kQuerySlow = 1, kQueryErrorTopN = 2, kQueryErrorArg = 3 };
 
@@ -89,7 +102,7 @@ struct ds_index {
     float sums_min = 0.f;
     ds::DeviceBuffer<uint32_t> col_ptr;    // [n_columns][n_tiles + 1], unit = quads of 4 postings (column-major)
     ds::DeviceBuffer<uint16_t> postings;   // [n_quads * 4] tile-local truth rows, kSentinel-padded per (column, tile)
-    ds::DeviceBuffer<uint16_t> posting_sums; // [n_quads * 4] bfloat16 (truncated = lower bound) of sums32[row], same order
+    ds::DeviceBuffer<uint16_t> posting_sums; // [n_quads * 4] per posting: 8-bit lower bound of sums32[row] << 8 | signature bits 0..7
     ds::DeviceBuffer<float> idf32;         // [n_columns]
     ds::DeviceBuffer<float> sums32;        // [n_truth]
     ds::DeviceBuffer<float> tile_sums_min; // [n_tiles] min(sums32) over the rows of each tile

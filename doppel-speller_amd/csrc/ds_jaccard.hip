@@ -56,13 +56,15 @@ struct JaccardArgs {
     int32_t n_tiles;
     int32_t k;
     int32_t sparse_quads;       // tiles with at most this many essential quads are handled sparsely
+    int32_t refine_batch;       // raw entries that trigger a refine pass
+    int32_t debug;              // timing experiments only (DS_DEBUG): 1 = skip sparse sweeps, 2 = skip exchange tests
     float sums_min;
 };
 
 // control words in HBM
 enum { kCtlQueue = 0, kCtlSlowCount = 1, kCtlErrors = 2, kCtlExact = 3, kCtlSelects = 4, kCtlSlowQueue = 5,
        kCtlSparseTiles = 6, kCtlDenseTiles = 7, kCtlSkippedColumns = 8, kCtlReason = 9 /* 9..14 */,
-       kCtlRefines = 16, kCtlRawEntries = 17, kCtlSearches = 18 };
+       kCtlRefines = 16, kCtlRawEntries = 17, kCtlSurvivors = 18, kCtlRawSparse = 19 };
 
 // LDS carve-up of the fast kernel (bytes)
 constexpr int kScoreFloats = kTile + 64;  // + trash slot for the padding entries of a quad
@@ -76,7 +78,9 @@ constexpr int kOffMass = kOffOrder + kMaxQueryColumns * 4;
 constexpr int kOffSigBit = kOffMass + kMaxQueryColumns * 4;
 constexpr int kOffBitIdf = kOffSigBit + kMaxQueryColumns * 4;
 constexpr int kOffFixed = kOffBitIdf + kSignatureBits * 4;
-constexpr int kOffBegin = kOffFixed + kMaxQueryColumns * 4;
+constexpr int kOffTotal = kOffFixed + kMaxQueryColumns * 4;
+constexpr int kOffMassTable = kOffTotal + kMaxQueryColumns * 4;
+constexpr int kOffBegin = kOffMassTable + 256 * 4;
 constexpr int kOffEnd = kOffBegin + kMaxQueryColumns * 4;
 constexpr int kOffPtr = kOffEnd + kMaxQueryColumns * 4;
 constexpr int kOffItems = kOffPtr + kMaxQueryColumns * (kPtrTiles + 1) * 4;
@@ -85,13 +89,16 @@ constexpr int kOffCtrl = kOffHist + 256 * 4;
 constexpr int kFastLdsBytes = kOffCtrl + 128;
 static_assert(kFastLdsBytes <= 160 * 1024, "LDS budget of one CU exceeded");
 static_assert(kMaxQueryColumns == 128 && kItemQuads == 256, "item encoding: 7 bits column, 5 bits chunk");
+constexpr int kRefineBatch = 256;  // raw entries that make a refine pass worth its three barriers
+constexpr int kRefineRoom = 640;   // refine when fewer free candidate slots than this remain
 constexpr int kKeep = (kCandidates + kThreads - 1) / kThreads;  // candidate entries a thread holds while compacting
 constexpr int kSelectTrigger = kCandidates - kLooseStep;
 constexpr int kWaves = kThreads / 64;
+constexpr int kUnits = kThreads >= 1024 ? 1 : 2;  // chunks of 4 quads per lane in flight per wave (register budget)
 
 // LDS control words
 enum { kLQuery = 0, kLCount, kLOverflow, kLDigit, kLRemain, kLCoef, kLPre, kLCut, kLKth0, kLKth1, kLBad, kLItems,
-       kLQuads, kLNonEssential, kLMass, kLUnsigned, kLSigMask /* 4 words */, kLEnd = kLSigMask + 4 };
+       kLQuads, kLNonEssential, kLMass, kLSparse, kLSigMask /* 4 words */, kLEnd = kLSigMask + 4 };
 
 __device__ __forceinline__ float round_down_positive(double x)
 {
@@ -163,6 +170,12 @@ struct Bounds {
     float maxint32;
 };
 
+// Inverse of encode_sums8: a lower bound of sums32[row] from the 8-bit code stored with every posting.
+__device__ __forceinline__ float decode_sums8(uint32_t code)
+{
+    return code == 0u ? 0.f : __uint_as_float((((code >> 4) + 124u) << 23) | ((code & 0xfu) << 19));
+}
+
 // Loose test: can the row still qualify if every skipped (non-essential) column matched as well?
 __device__ __forceinline__ bool may_qualify(float s, float sums, const Bounds &b)
 {
@@ -179,20 +192,16 @@ __device__ __forceinline__ bool candidate_key(float s, float sums, const Bounds 
     return true;
 }
 
-// What the skipped columns of a tile look like to the completion step.
+// The skipped (non-essential) columns: ranks 0..count-1 of the ascending-IDF order.  Only columns that own a
+// signature bit are ever skipped, so completing a score is one 16-byte load per row.
 struct Skipped {
-    int count;           // ranks 0..count-1 of the ascending-IDF order are skipped
-    uint32_t sig_mask[kSignatureWords];  // signature bits of the skipped columns that have one
-    int without_bit;     // skipped columns without a signature bit (need a binary search)
+    int count;
+    uint32_t sig_mask[kSignatureWords];
 };
 
-// Adds what the skipped columns contribute to row t (tile-local `local`): one signature load for the dense columns,
-// a binary search in the (column, tile) sub-list for the others.  Approximate (order-free) like the scatter itself.
-// Called by the few lanes whose row passed the loose test.
-__device__ __forceinline__ float complete_score(float s, uint4 signature, uint32_t local, const Skipped &skipped,
-                                                int bt, const int32_t *order, const int32_t *sig_bit,
-                                                const float *bit_idf, const uint32_t *ptr_cache, const float *idf,
-                                                const uint16_t *postings)
+// Adds what the skipped columns contribute to a row, from its membership signature.  Approximate (order-free) like
+// the scatter itself.
+__device__ __forceinline__ float complete_score(float s, uint4 signature, const Skipped &skipped, const float *bit_idf)
 {
     const uint32_t words[kSignatureWords] = {signature.x, signature.y, signature.z, signature.w};
 #pragma unroll
@@ -201,20 +210,6 @@ __device__ __forceinline__ float complete_score(float s, uint4 signature, uint32
         while (bits) {
             s += bit_idf[w * 32 + __ffs(bits) - 1];
             bits &= bits - 1u;
-        }
-    }
-    if (skipped.without_bit > 0) {
-        for (int r = 0; r < skipped.count; ++r) {
-            const int j = order[r];
-            if (sig_bit[j] >= 0) continue;
-            uint32_t lo = ptr_cache[j * (kPtrTiles + 1) + bt] * 4u;
-            const uint32_t end = ptr_cache[j * (kPtrTiles + 1) + bt + 1] * 4u;
-            uint32_t hi = end;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (postings[mid] < local) lo = mid + 1; else hi = mid;
-            }
-            if (lo < end && postings[lo] == local) s += idf[j];
         }
     }
     return s;
@@ -267,6 +262,9 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
     float *bit_idf = reinterpret_cast<float *>(lds + kOffBitIdf);     // IDF of the query column owning signature bit g
     uint32_t *fixed = reinterpret_cast<uint32_t *>(lds + kOffFixed);  // idf[j] in the query's fixed-point scale
     uint32_t *iscores = reinterpret_cast<uint32_t *>(lds);           // the score tile holds fixed-point sums
+    uint32_t *col_total = reinterpret_cast<uint32_t *>(lds + kOffTotal);  // quads of column j over all tiles
+    // mass_table[b] = upper bound of what the skipped columns add to a row whose signature bits 0..7 are b
+    float *mass_table = reinterpret_cast<float *>(lds + kOffMassTable);
     uint32_t *list_begin = reinterpret_cast<uint32_t *>(lds + kOffBegin);
     uint32_t *list_end = reinterpret_cast<uint32_t *>(lds + kOffEnd);
     uint32_t *ptr_cache = reinterpret_cast<uint32_t *>(lds + kOffPtr);  // [column][kPtrTiles + 1]
@@ -309,6 +307,9 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             const float value = bad ? 0.f : a.idf32[column];
             const int bit = bad ? -1 : static_cast<int>(a.sig_column[column]);
             idf[tid] = value;
+            col_total[tid] = bad ? 0u
+                                 : a.col_ptr[static_cast<int64_t>(column) * ptr_stride + a.n_tiles] -
+                                       a.col_ptr[static_cast<int64_t>(column) * ptr_stride];
             sig_bit[tid] = bit;
             if (bit >= 0) bit_idf[bit] = value;
         }
@@ -351,13 +352,71 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
         Bounds bounds{0.f, FLT_MIN, 0.f, maxint32};
         float cut = 0.f, pending_mass = 0.f;  // mass of the columns skipped from the NEXT tile on
         uint32_t pending_sig_mask[kSignatureWords] = {0u, 0u, 0u, 0u};
-        int pending_without_bit = 0;
+        Skipped skipped{0, {0u, 0u, 0u, 0u}};
+        bool sparse_mode = false;  // decided at every selection from the essential columns' remaining length
+        bool rebuild_mass_table = false;
+        int first_raw = 0;  // candidate entries [first_raw, count) are RAW: not yet refined
+        const int refine_batch = a.refine_batch;
         int non_essential = 0;
         bool tight = false;
         int next_select = max(4 * k, 64);
         if (next_select > kSelectTrigger) next_select = kSelectTrigger;
         int selects = 0, sparse_tiles = 0, dense_tiles = 0;
         DS_STAMP(0);
+
+        // `refine` turns the RAW entries (approximate essential score, row) appended by the sweeps into candidates:
+        // exact sums, completion of the skipped columns from the signature, tight test -- one thread per entry --
+        // or drops them.  Deferred until enough raw entries exist; always runs before a selection, so every raw
+        // entry was produced under the current `skipped` set.  Called by all threads after a barrier; ends with one.
+        auto refine = [&]() {
+            const int last_raw = min(static_cast<int>(ctrl[kLCount]), kCandidates);
+            if (last_raw <= first_raw) return;
+            if (tid == 0 && a.phase != nullptr) {
+                atomicAdd(&a.control[kCtlRefines], 1);
+                atomicAdd(&a.control[kCtlRawEntries], last_raw - first_raw);
+            }
+            uint32_t keep_key[kKeep];
+            int32_t keep_row[kKeep];
+#pragma unroll
+            for (int r = 0; r < kKeep; ++r) {
+                const int i = first_raw + tid + r * kThreads;
+                keep_row[r] = -1;
+                keep_key[r] = 0u;
+                const int32_t t = i < last_raw ? cand_row[i] : -1;
+                if (t >= 0) {
+                    const float raw = __uint_as_float(cand_key[i]);
+                    const float sums = a.sums32[t];
+                    const uint4 signature = skipped.count > 0 ? a.signature[t] : make_uint4(0u, 0u, 0u, 0u);
+                    if (may_qualify(raw, sums, bounds)) {
+                        const float full = complete_score(raw, signature, skipped, bit_idf);
+                        uint32_t key = 0;
+                        if (candidate_key(full, sums, bounds, key)) {
+                            keep_key[r] = key;
+                            keep_row[r] = t;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) ctrl[kLCount] = first_raw;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kKeep; ++r) {
+                if (keep_row[r] >= 0) {
+                    const int slot = atomicAdd(const_cast<int32_t *>(&ctrl[kLCount]), 1);
+                    cand_key[slot] = keep_key[r];
+                    cand_row[slot] = keep_row[r];
+                }
+            }
+            __syncthreads();
+            if (tid == 0 && a.phase != nullptr) atomicAdd(&a.control[kCtlSurvivors], ctrl[kLCount] - first_raw);
+            first_raw = ctrl[kLCount];
+        };
+        // refine when raw entries pile up, when a selection is due, or when the buffer runs short of room
+        auto refine_due = [&]() {
+            const int count = ctrl[kLCount];
+            return count - first_raw >= refine_batch || count > kCandidates - kRefineRoom;
+        };
 
         for (int b = 0; b < a.n_tiles && !slow; ++b) {
             const int bt = b % kPtrTiles;
@@ -371,89 +430,65 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                 __syncthreads();
             }
             // ---- work items of this tile: (column, chunk of kItemQuads quads) for every essential column
+            // raw entries were scored under the current set of skipped columns: refine them before it changes
+            if (non_essential != skipped.count && first_raw != ctrl[kLCount]) refine();
             bounds.mass = pending_mass;  // what this tile's scores do NOT contain; fixed until the tile is done
-            const Skipped skipped{non_essential,
-                                  {pending_sig_mask[0], pending_sig_mask[1], pending_sig_mask[2], pending_sig_mask[3]},
-                                  pending_without_bit};
-            if (wave == 0) {
-                uint32_t length[2], count[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int j = lane + 64 * h;
-                    uint32_t begin = 0, end = 0;
-                    if (j < n && rank[j] >= non_essential) {
-                        begin = ptr_cache[j * (kPtrTiles + 1) + bt];
-                        end = ptr_cache[j * (kPtrTiles + 1) + bt + 1];
+            skipped.count = non_essential;
+            for (int w = 0; w < kSignatureWords; ++w) skipped.sig_mask[w] = pending_sig_mask[w];
+            if (rebuild_mass_table) {  // used by the exchange sweep, i.e. after the barrier that ends the scatter
+                rebuild_mass_table = false;
+                if (tid < 256) {
+                    const uint32_t skipped8 = skipped.sig_mask[0] & 0xffu;
+                    double rest = static_cast<double>(bounds.mass), some = 0.0;
+                    for (int g = 0; g < 8; ++g) {
+                        if (!((skipped8 >> g) & 1u)) continue;
+                        rest -= static_cast<double>(bit_idf[g]);
+                        if ((tid >> g) & 1) some += static_cast<double>(bit_idf[g]);
                     }
-                    list_begin[j] = begin;
-                    list_end[j] = end;
-                    length[h] = end - begin;
-                    count[h] = (length[h] + kItemQuads - 1) / kItemQuads;
-                }
-                const uint32_t scan0 = wave_inclusive_scan(count[0], lane);
-                const uint32_t total0 = __shfl(scan0, 63);
-                const uint32_t scan1 = wave_inclusive_scan(count[1], lane);
-                const uint32_t total1 = __shfl(scan1, 63);
-                const uint32_t n_items = total0 + total1;
-                uint32_t quads_here = length[0] + length[1];
-                for (int d = 32; d > 0; d >>= 1) quads_here += __shfl_xor(quads_here, d);
-                if (n_items <= kMaxItems) {
-                    uint32_t at = scan0 - count[0];
-                    for (uint32_t c = 0; c < count[0]; ++c) items[at + c] = static_cast<uint16_t>(lane | (c << 7));
-                    at = total0 + scan1 - count[1];
-                    for (uint32_t c = 0; c < count[1]; ++c)
-                        items[at + c] = static_cast<uint16_t>((lane + 64) | (c << 7));
-                }
-                if (lane == 0) {
-                    ctrl[kLItems] = static_cast<int32_t>(n_items);
-                    ctrl[kLQuads] = static_cast<int32_t>(quads_here);
+                    if (rest < 0.0) rest = 0.0;
+                    // rounded up, and never above the full mass (which already carries its own slack)
+                    const float value = round_up_positive((rest + some) * (1.0 + 3.814697265625e-06) + 1e-30);
+                    mass_table[tid] = value < bounds.mass ? value : bounds.mass;
                 }
             }
-            __syncthreads();
-            const int n_items = ctrl[kLItems];
-            if (n_items > kMaxItems) { slow = true; reason = 1; break; }
-            const bool sparse = tight && ctrl[kLQuads] <= a.sparse_quads;
+            const bool sparse = tight && sparse_mode;
+            int n_items = 0;
+            if (!sparse) {
+                if (wave == 0) {
+                    uint32_t length[2], count[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int j = lane + 64 * h;
+                        uint32_t begin = 0, end = 0;
+                        if (j < n && rank[j] >= non_essential) {
+                            begin = ptr_cache[j * (kPtrTiles + 1) + bt];
+                            end = ptr_cache[j * (kPtrTiles + 1) + bt + 1];
+                        }
+                        list_begin[j] = begin;
+                        list_end[j] = end;
+                        length[h] = end - begin;
+                        count[h] = (length[h] + kItemQuads - 1) / kItemQuads;
+                    }
+                    const uint32_t scan0 = wave_inclusive_scan(count[0], lane);
+                    const uint32_t total0 = __shfl(scan0, 63);
+                    const uint32_t scan1 = wave_inclusive_scan(count[1], lane);
+                    const uint32_t total1 = __shfl(scan1, 63);
+                    const uint32_t total_items = total0 + total1;
+                    if (total_items <= kMaxItems) {
+                        uint32_t at = scan0 - count[0];
+                        for (uint32_t c = 0; c < count[0]; ++c)
+                            items[at + c] = static_cast<uint16_t>(lane | (c << 7));
+                        at = total0 + scan1 - count[1];
+                        for (uint32_t c = 0; c < count[1]; ++c)
+                            items[at + c] = static_cast<uint16_t>((lane + 64) | (c << 7));
+                    }
+                    if (lane == 0) ctrl[kLItems] = static_cast<int32_t>(total_items);
+                }
+                __syncthreads();
+                n_items = ctrl[kLItems];
+                if (n_items > kMaxItems) { slow = true; reason = 1; break; }
+            }
             DS_STAMP(1);
-
-            // ---- (1) scatter: fixed-point LDS atomics (ds_add_u32); padding entries hit the trash slot scores[kTile].
-            // A wave owns whole items; two items (up to 8 quad loads per lane) are in flight at a time.  When the
-            // whole tile is a single batch the quads stay in registers for the exchange sweep.
-            const bool single_batch = n_items <= 2 * kWaves;
-            uint2 quad[8], quad_sums[8];
-            bool live[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) live[u] = false;
-            for (int it = wave; it < n_items; it += 2 * kWaves) {
-                uint32_t value[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int at = it + h * kWaves;
-                    const bool item_ok = at < n_items;
-                    const uint32_t item = item_ok ? items[at] : 0u;
-                    const int j = item & 127u;
-                    const uint32_t first = list_begin[j] + (item >> 7) * kItemQuads + lane;
-                    const uint32_t end = item_ok ? list_end[j] : 0u;
-                    value[h] = fixed[j];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t index = first + u * 64;
-                        live[h * 4 + u] = index < end;
-                        quad[h * 4 + u] = live[h * 4 + u] ? quads[index] : make_uint2(0x80008000u, 0x80008000u);
-                        if (sparse && single_batch && live[h * 4 + u]) quad_sums[h * 4 + u] = sums_quads[index];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (!live[u]) continue;
-                    const uint32_t v = value[u >> 2];
-                    atomicAdd(&iscores[quad[u].x & 0xffffu], v);
-                    atomicAdd(&iscores[quad[u].x >> 16], v);
-                    atomicAdd(&iscores[quad[u].y & 0xffffu], v);
-                    atomicAdd(&iscores[quad[u].y >> 16], v);
-                }
-            }
-            __syncthreads();
-            DS_STAMP(sparse ? 6 : 2);
 
             const int64_t tile_base = static_cast<int64_t>(b) << kTileLog2;
             // row-independent gate of this tile: coef * (min sums of the tile + maxint), rounded down
@@ -463,108 +498,143 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                 if (gate > here.pre) here.pre = gate;
             }
             // A sweep only runs the register-level tests and appends RAW entries (approximate essential score, row);
-            // `refine` then turns the raw entries of the sweep into candidates (exact sums, completion of the skipped
-            // columns, tight test) with one thread per entry, or drops them.
-            auto consider = [&](float s, uint32_t local, bool have_bound, float sums_lower_bound) {
-                bool pass = s > 0.f && s + here.mass >= here.pre;
-                // sparse sweep: the posting carries a bfloat16 lower bound of sums[t] (no gather)
-                if (have_bound) pass = pass && may_qualify(s, sums_lower_bound, here);
-                append_candidate(pass, __float_as_uint(s), static_cast<int32_t>(tile_base + local), cand_key,
-                                 cand_row, ctrl, lane);
+            // `refine` later turns raw entries into candidates or drops them.
+            auto passes = [&](float s, float sums_lower_bound, float row_mass) {
+                return s > 0.f && s + row_mass >= here.pre &&
+                       s + row_mass >= here.coef * (sums_lower_bound + here.maxint32);
             };
-            auto refine = [&](int first_raw) {  // called by all threads after a barrier; ends with a barrier
-                const int last_raw = min(static_cast<int>(ctrl[kLCount]), kCandidates);
-                if (last_raw <= first_raw) return;
-                if (tid == 0 && a.phase != nullptr) {
-                    atomicAdd(&a.control[kCtlRefines], 1);
-                    atomicAdd(&a.control[kCtlRawEntries], last_raw - first_raw);
-                    if (skipped.without_bit > 0) atomicAdd(&a.control[kCtlSearches], 1);
-                }
-                uint32_t keep_key[kKeep];
-                int32_t keep_row[kKeep];
+            // four rows at a time: one ballot decides whether anything needs appending (the common case: nothing)
+            auto consider4 = [&](const float (&s)[4], const uint32_t (&local)[4], const float (&sums_lower_bound)[4],
+                                 const float (&row_mass)[4]) {
+                bool pass[4];
 #pragma unroll
-                for (int r = 0; r < kKeep; ++r) {
-                    const int i = first_raw + tid + r * kThreads;
-                    keep_row[r] = -1;
-                    keep_key[r] = 0u;
-                    if (i < last_raw) {
-                        const int32_t t = cand_row[i];
-                        const float raw = __uint_as_float(cand_key[i]);
-                        const float sums = a.sums32[t];
-                        const uint4 signature = skipped.count > 0 ? a.signature[t] : make_uint4(0u, 0u, 0u, 0u);
-                        if (may_qualify(raw, sums, here)) {
-                            const float full =
-                                complete_score(raw, signature, static_cast<uint32_t>(t - tile_base), skipped, bt, order,
-                                               sig_bit, bit_idf, ptr_cache, idf, a.postings);
-                            uint32_t key = 0;
-                            if (candidate_key(full, sums, here, key)) {
-                                keep_key[r] = key;
-                                keep_row[r] = t;
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-                if (tid == 0) ctrl[kLCount] = first_raw;
-                __syncthreads();
+                for (int e = 0; e < 4; ++e) pass[e] = passes(s[e], sums_lower_bound[e], row_mass[e]);
+                if (__ballot(pass[0] || pass[1] || pass[2] || pass[3]) == 0) return;
 #pragma unroll
-                for (int r = 0; r < kKeep; ++r) {
-                    if (keep_row[r] >= 0) {
-                        const int slot = atomicAdd(const_cast<int32_t *>(&ctrl[kLCount]), 1);
-                        cand_key[slot] = keep_key[r];
-                        cand_row[slot] = keep_row[r];
-                    }
-                }
-                __syncthreads();
+                for (int e = 0; e < 4; ++e)
+                    append_candidate(pass[e], __float_as_uint(s[e]), static_cast<int32_t>(tile_base + local[e]),
+                                     cand_key, cand_row, ctrl, lane);
             };
-            int first_raw = ctrl[kLCount];
+
             if (sparse) {
-                // ---- (2s) exchange sweep over the same postings: the first lane to reach a row takes its score and
-                // leaves zero behind; rows that can still qualify become candidates
+                // ---- sparse tile: wave w owns the essential columns w, w + kWaves, ...; no item list, two barriers.
+                // (1s) scatter with fixed-point LDS atomics; (2s) exchange sweep over the same postings: the first
+                // lane to reach a row takes its score and leaves zero behind.  Two chunks (8 quads per lane) are in
+                // flight at a time.
                 ++sparse_tiles;
-                for (int it = wave; it < n_items; it += 2 * kWaves) {
-                    if (!single_batch) {
+                const int count_before = ctrl[kLCount];
+#pragma unroll 1
+                for (int sweep = 0; sweep < 2; ++sweep) {
+                    int j = (a.debug & 1) ? n : wave;
+                    uint32_t position = 0;
+                    for (;;) {
+                        uint32_t first[kUnits], last[kUnits], value[kUnits];
+                        int units = 0;
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int at = it + h * kWaves;
-                            const bool item_ok = at < n_items;
-                            const uint32_t item = item_ok ? items[at] : 0u;
-                            const int j = item & 127u;
-                            const uint32_t first = list_begin[j] + (item >> 7) * kItemQuads + lane;
-                            const uint32_t end = item_ok ? list_end[j] : 0u;
+                        for (int h = 0; h < kUnits; ++h) {
+                            first[h] = last[h] = value[h] = 0u;
+                            while (j < n) {
+                                const uint32_t begin = ptr_cache[j * (kPtrTiles + 1) + bt] + position;
+                                const uint32_t end = ptr_cache[j * (kPtrTiles + 1) + bt + 1];
+                                if (rank[j] >= non_essential && begin < end) {
+                                    first[h] = begin;
+                                    last[h] = end;
+                                    value[h] = fixed[j];
+                                    position += kItemQuads;
+                                    ++units;
+                                    break;
+                                }
+                                j += kWaves;
+                                position = 0;
+                            }
+                        }
+                        if (units == 0) break;
+                        uint2 quad[4 * kUnits], quad_sums[4 * kUnits];
+                        bool live[4 * kUnits];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const uint32_t index = first + u * 64;
-                                live[h * 4 + u] = index < end;
-                                quad[h * 4 + u] =
-                                    live[h * 4 + u] ? quads[index] : make_uint2(0x80008000u, 0x80008000u);
-                                if (live[h * 4 + u]) quad_sums[h * 4 + u] = sums_quads[index];
+                        for (int u = 0; u < 4 * kUnits; ++u) {
+                            const uint32_t index = first[u >> 2] + (u & 3) * 64 + lane;
+                            live[u] = index < last[u >> 2];
+                            quad[u] = live[u] ? quads[index] : make_uint2(0x80008000u, 0x80008000u);
+                            if (sweep == 1 && live[u]) quad_sums[u] = sums_quads[index];
+                        }
+                        if (sweep == 0) {
+#pragma unroll
+                            for (int u = 0; u < 4 * kUnits; ++u) {
+                                if (!live[u]) continue;
+                                const uint32_t v = value[u >> 2];
+                                atomicAdd(&iscores[quad[u].x & 0xffffu], v);
+                                atomicAdd(&iscores[quad[u].x >> 16], v);
+                                atomicAdd(&iscores[quad[u].y & 0xffffu], v);
+                                atomicAdd(&iscores[quad[u].y >> 16], v);
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 4 * kUnits; ++u) {
+                                if (__ballot(live[u]) == 0) continue;
+                                const uint32_t local[4] = {quad[u].x & 0xffffu, quad[u].x >> 16, quad[u].y & 0xffffu,
+                                                           quad[u].y >> 16};
+                                const uint32_t info[4] = {quad_sums[u].x & 0xffffu, quad_sums[u].x >> 16,
+                                                          quad_sums[u].y & 0xffffu, quad_sums[u].y >> 16};
+                                uint32_t taken[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    taken[e] = (live[u] && local[e] < kTile) ? atomicExch(&iscores[local[e]], 0u) : 0u;
+                                if (!(a.debug & 2)) {
+                                    const float s4[4] = {static_cast<float>(taken[0]) * from_fixed,
+                                                         static_cast<float>(taken[1]) * from_fixed,
+                                                         static_cast<float>(taken[2]) * from_fixed,
+                                                         static_cast<float>(taken[3]) * from_fixed};
+                                    const float bound4[4] = {decode_sums8(info[0] >> 8), decode_sums8(info[1] >> 8),
+                                                             decode_sums8(info[2] >> 8), decode_sums8(info[3] >> 8)};
+                                    const float mass4[4] = {mass_table[info[0] & 0xffu], mass_table[info[1] & 0xffu],
+                                                            mass_table[info[2] & 0xffu], mass_table[info[3] & 0xffu]};
+                                    consider4(s4, local, bound4, mass4);
+                                }
                             }
                         }
                     }
+                    __syncthreads();
+                    DS_STAMP(sweep == 0 ? 6 : 7);
+                }
+                if (ctrl[kLOverflow]) { slow = true; reason = 2; break; }
+                if (tid == 0 && a.phase != nullptr) atomicAdd(&a.control[kCtlRawSparse], ctrl[kLCount] - count_before);
+                if (refine_due()) refine();
+            } else {
+                // ---- dense tile (1) scatter: fixed-point LDS atomics (ds_add_u32); padding entries hit the trash slot
+                // scores[kTile].  A wave owns whole items; two items (up to 8 quad loads per lane) are in flight.
+                for (int it = wave; it < n_items; it += kUnits * kWaves) {
+                    uint2 quad[4 * kUnits];
+                    bool live[4 * kUnits];
+                    uint32_t value[kUnits];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (__ballot(live[u]) == 0) continue;
-                        const uint32_t local[4] = {quad[u].x & 0xffffu, quad[u].x >> 16, quad[u].y & 0xffffu,
-                                                   quad[u].y >> 16};
-                        const float bound[4] = {__uint_as_float(quad_sums[u].x << 16),
-                                                __uint_as_float(quad_sums[u].x & 0xffff0000u),
-                                                __uint_as_float(quad_sums[u].y << 16),
-                                                __uint_as_float(quad_sums[u].y & 0xffff0000u)};
-                        uint32_t taken[4];
+                    for (int h = 0; h < kUnits; ++h) {
+                        const int at = it + h * kWaves;
+                        const bool item_ok = at < n_items;
+                        const uint32_t item = item_ok ? items[at] : 0u;
+                        const int j = item & 127u;
+                        const uint32_t first = list_begin[j] + (item >> 7) * kItemQuads + lane;
+                        const uint32_t end = item_ok ? list_end[j] : 0u;
+                        value[h] = fixed[j];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            taken[e] = (live[u] && local[e] < kTile) ? atomicExch(&iscores[local[e]], 0u) : 0u;
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t index = first + u * 64;
+                            live[h * 4 + u] = index < end;
+                            if (live[h * 4 + u]) quad[h * 4 + u] = quads[index];
+                        }
+                    }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            consider(static_cast<float>(taken[e]) * from_fixed, local[e], true, bound[e]);
+                    for (int u = 0; u < 4 * kUnits; ++u) {
+                        if (!live[u]) continue;
+                        const uint32_t v = value[u >> 2];
+                        atomicAdd(&iscores[quad[u].x & 0xffffu], v);
+                        atomicAdd(&iscores[quad[u].x >> 16], v);
+                        atomicAdd(&iscores[quad[u].y & 0xffffu], v);
+                        atomicAdd(&iscores[quad[u].y >> 16], v);
                     }
                 }
                 __syncthreads();
-                if (ctrl[kLOverflow]) { slow = true; reason = 2; break; }
-                refine(first_raw);
-                first_raw = ctrl[kLCount];
-                DS_STAMP(7);
+                DS_STAMP(2);
             }
 
             // ---- (2d) dense scan (and re-zero) of the tile; in steps while no running value exists
@@ -572,7 +642,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             const int limit = rows_left >= kTile ? kTile : static_cast<int>((rows_left + 3) & ~int64_t(3));
             int r0 = sparse ? limit : 0;
             if (!sparse) ++dense_tiles;
-            bool select_now = sparse && ctrl[kLCount] >= next_select;
+            bool select_now = sparse && first_raw == ctrl[kLCount] && ctrl[kLCount] >= next_select;
             while (r0 < limit || select_now) {
                 if (r0 < limit) {
                     const int r1 = tight ? limit : min(r0 + kLooseStep, limit);
@@ -589,21 +659,22 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                         if (__ballot(any) == 0) continue;
                         // sums of the four rows in one coalesced load (the array is padded by four entries)
                         const float4 sums4 = *reinterpret_cast<const float4 *>(&a.sums32[tile_base + idx]);
-                        consider(s4.x, static_cast<uint32_t>(idx), true, sums4.x);
-                        consider(s4.y, static_cast<uint32_t>(idx + 1), true, sums4.y);
-                        consider(s4.z, static_cast<uint32_t>(idx + 2), true, sums4.z);
-                        consider(s4.w, static_cast<uint32_t>(idx + 3), true, sums4.w);
+                        const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+                        const uint32_t rows4[4] = {static_cast<uint32_t>(idx), static_cast<uint32_t>(idx + 1),
+                                                   static_cast<uint32_t>(idx + 2), static_cast<uint32_t>(idx + 3)};
+                        const float bound4[4] = {sums4.x, sums4.y, sums4.z, sums4.w};
+                        const float mass4[4] = {here.mass, here.mass, here.mass, here.mass};
+                        consider4(sv, rows4, bound4, mass4);
                     }
                     __syncthreads();
                     r0 = r1;
                     if (ctrl[kLOverflow]) { slow = true; reason = 3; break; }
-                    refine(first_raw);
-                    first_raw = ctrl[kLCount];
+                    if (!tight || refine_due()) refine();
                     DS_STAMP(3);
                 }
                 select_now = false;
                 const int m = ctrl[kLCount];
-                if (m < next_select) continue;
+                if (m < next_select || first_raw != m) continue;  // raw entries are refined before any selection
                 // ---- tighten: tau = k-th largest lower estimate seen so far; keep what can still qualify
                 const uint32_t tau_key = radix_select_kth(cand_key, m, k, hist, ctrl);
                 ++selects;
@@ -621,31 +692,40 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                         new_pre = p > static_cast<double>(FLT_MIN) ? round_down_positive(p) : FLT_MIN;
                     }
                     // non-essential columns: the longest ascending-IDF prefix whose total mass stays below `pre`
+                    // and whose columns all own a signature bit (completion is then a single load per row)
                     int skip_count = 0;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int r = lane + 64 * h;
-                        skip_count += __popcll(__ballot(r < n && mass_upto[r] < new_pre));
+                    {
+                        const bool ok0 = lane < n && mass_upto[lane] < new_pre && sig_bit[order[lane]] >= 0;
+                        const bool ok1 = lane + 64 < n && mass_upto[lane + 64] < new_pre && sig_bit[order[lane + 64]] >= 0;
+                        const unsigned long long v0 = __ballot(ok0), v1 = __ballot(ok1);
+                        skip_count = ~v0 ? __ffsll(static_cast<long long>(~v0)) - 1
+                                         : 64 + (~v1 ? __ffsll(static_cast<long long>(~v1)) - 1 : 64);
                     }
                     uint32_t mask_bits[kSignatureWords] = {0u, 0u, 0u, 0u};
-                    int without_bit = 0;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int r = lane + 64 * h;
-                        const int bit = r < skip_count ? sig_bit[order[r]] : 0;
-                        if (r < skip_count && bit >= 0) {
+                        if (r < skip_count) {
+                            const int bit = sig_bit[order[r]];
 #pragma unroll
                             for (int w = 0; w < kSignatureWords; ++w)
                                 if ((bit >> 5) == w) mask_bits[w] |= 1u << (bit & 31);
                         }
-                        without_bit += __popcll(__ballot(r < skip_count && bit < 0));
                     }
 #pragma unroll
                     for (int w = 0; w < kSignatureWords; ++w)
                         for (int d = 32; d > 0; d >>= 1) mask_bits[w] |= __shfl_xor(mask_bits[w], d);
+                    uint32_t essential_quads = 0;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int j = lane + 64 * h;
+                        if (j < n && rank[j] >= skip_count) essential_quads += col_total[j];
+                    }
+                    for (int d = 32; d > 0; d >>= 1) essential_quads += __shfl_xor(essential_quads, d);
                     if (lane == 0) {
+                        ctrl[kLSparse] = essential_quads / static_cast<uint32_t>(a.n_tiles) <=
+                                         static_cast<uint32_t>(a.sparse_quads);
                         for (int w = 0; w < kSignatureWords; ++w) ctrl[kLSigMask + w] = static_cast<int32_t>(mask_bits[w]);
-                        ctrl[kLUnsigned] = without_bit;
                         ctrl[kLCoef] = __float_as_int(new_coef);
                         ctrl[kLPre] = __float_as_int(new_pre);
                         ctrl[kLCut] = __float_as_int(new_cut);
@@ -662,10 +742,11 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     here.pre = gate > bounds.pre ? gate : bounds.pre;
                 }
                 pending_mass = __int_as_float(ctrl[kLMass]);
+                rebuild_mass_table = true;
                 for (int w = 0; w < kSignatureWords; ++w) pending_sig_mask[w] = static_cast<uint32_t>(ctrl[kLSigMask + w]);
-                pending_without_bit = ctrl[kLUnsigned];
                 cut = __int_as_float(ctrl[kLCut]);
                 non_essential = ctrl[kLNonEssential];
+                sparse_mode = ctrl[kLSparse] != 0;
                 tight = true;
                 // in-place compaction: read everything, barrier, rewrite the survivors
                 uint32_t keep_key[kKeep];
@@ -696,6 +777,10 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             }
         }
 
+        if (!slow) {
+            __syncthreads();
+            refine();
+        }
         int m = slow ? 0 : ctrl[kLCount];
         if (!slow && m < k) { slow = true; reason = 5; }  // fewer than k positive rows: literal path decides
         if (!slow) {
@@ -1019,6 +1104,10 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     args.sparse_quads = 4096;
     if (const char *limit = getenv("DS_SPARSE_QUADS"); limit != nullptr) args.sparse_quads = atoi(limit);
     args.sums_min = index->sums_min;
+    args.debug = 0;
+    args.refine_batch = kRefineBatch;
+    if (const char *batch = getenv("DS_REFINE_BATCH"); batch != nullptr) args.refine_batch = atoi(batch);
+    if (const char *debug = getenv("DS_DEBUG"); debug != nullptr) args.debug = atoi(debug);
 
     const int grid = static_cast<int>(std::min<int64_t>(Q, index->compute_units));
     DS_HIP(hipMemsetAsync(index->control.ptr, 0, kControlWords * sizeof(int32_t), stream));
@@ -1054,8 +1143,9 @@ static int collect(ds_index *index, hipStream_t stream, int64_t stats[32])
         for (int i = 0; i < 6; ++i) stats[16 + i] = control[kCtlReason + i];
         stats[22] = control[kCtlRefines];
         stats[23] = control[kCtlRawEntries];
-        stats[24] = control[kCtlSearches];
-        for (int i = 25; i < 32; ++i) stats[i] = 0;
+        stats[24] = control[kCtlSurvivors];
+        stats[25] = control[kCtlRawSparse];
+        for (int i = 26; i < 32; ++i) stats[i] = 0;
     }
     if (control[kCtlErrors] != 0 && index->last_queries > 0) {
         std::vector<int32_t> status(static_cast<size_t>(index->last_queries));

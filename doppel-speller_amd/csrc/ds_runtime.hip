@@ -95,26 +95,6 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
         }
         row[n_tiles] = static_cast<uint32_t>(quads);
     }
-    // pass 2: fill
-    std::vector<uint16_t> postings(static_cast<size_t>(quads) * 4, static_cast<uint16_t>(ds::kSentinel));
-    std::vector<uint16_t> posting_sums(static_cast<size_t>(quads) * 4, static_cast<uint16_t>(0x7f7f));
-    for (int64_t g = 0; g < V; ++g) {
-        const uint32_t *row = col_ptr.data() + g * stride;
-        int64_t current_tile = -1;
-        uint64_t write = 0;
-        for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
-            const int64_t t = truth_idx[p];
-            const int64_t b = t >> ds::kTileLog2;
-            if (b != current_tile) {
-                current_tile = b;
-                write = static_cast<uint64_t>(row[b]) * 4u;
-            }
-            uint32_t sums_bits;
-            std::memcpy(&sums_bits, &sums32[t], sizeof(sums_bits));
-            posting_sums[write] = static_cast<uint16_t>(sums32[t] > 0.f ? sums_bits >> 16 : 0u);  // truncation: <= sums
-            postings[write++] = static_cast<uint16_t>(t & (ds::kTile - 1));
-        }
-    }
     float sums_min = sums32[0];
     std::vector<float> tile_sums_min(static_cast<size_t>(n_tiles), 0.f);
     for (int64_t b = 0; b < n_tiles; ++b) {
@@ -145,6 +125,25 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
         }
     }
 
+    // pass 2: fill
+    std::vector<uint16_t> postings(static_cast<size_t>(quads) * 4, static_cast<uint16_t>(ds::kSentinel));
+    std::vector<uint16_t> posting_sums(static_cast<size_t>(quads) * 4, static_cast<uint16_t>(0xff00));
+    for (int64_t g = 0; g < V; ++g) {
+        const uint32_t *row = col_ptr.data() + g * stride;
+        int64_t current_tile = -1;
+        uint64_t write = 0;
+        for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
+            const int64_t t = truth_idx[p];
+            const int64_t b = t >> ds::kTileLog2;
+            if (b != current_tile) {
+                current_tile = b;
+                write = static_cast<uint64_t>(row[b]) * 4u;
+            }
+            posting_sums[write] = static_cast<uint16_t>((ds::encode_sums8(sums32[t]) << 8) |
+                                                         (signature[static_cast<size_t>(t) * ds::kSignatureWords] & 0xffu));
+            postings[write++] = static_cast<uint16_t>(t & (ds::kTile - 1));
+        }
+    }
     DS_HIP(hipSetDevice(device));
     hipDeviceProp_t properties;
     DS_HIP(hipGetDeviceProperties(&properties, device));

@@ -99,7 +99,8 @@ class TruthIndex:
                 "sparse_tiles": stats[12], "dense_tiles": stats[13], "skipped_columns": stats[14],
                 "dense_reasons": dict(zip(("shape", "items", "overflow_sparse", "overflow_dense", "ties", "few"),
                                           list(stats)[16:22])),
-                "refines": stats[22], "raw_entries": stats[23], "refines_with_search": stats[24]}
+                "refines": stats[22], "raw_entries": stats[23], "refine_survivors": stats[24],
+                "raw_entries_sparse": stats[25]}
 
     def close(self):
         if self.handle:
