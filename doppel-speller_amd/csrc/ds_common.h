@@ -28,7 +28,9 @@ constexpr int kMaxItems = 512;               // work items per (query, tile); mo
 constexpr int kSignatureBits = 128;          // densest columns whose membership is kept as a per-row bit (uint4)
 constexpr int kSignatureWords = kSignatureBits / 32;
 constexpr int kControlWords = 32;            // int32 control block in HBM (queue heads, counters)
-constexpr int kSlowSlots = 64;               // concurrent queries of the exact dense kernel (scratch = slots*N*8 B)
+constexpr int kSlowSlotsMax = 256;           // concurrent queries of the exact dense kernel (scratch = slots*N*8 B)
+constexpr int kSlowSlotsMin = 16;
+constexpr int64_t kSlowScratchBytes = int64_t(8) << 30;  // scratch budget that sizes the number of slots
 
 // 8-bit lower bound of a positive float: 4 exponent bits (2^-3 .. 2^12) and 4 mantissa bits, truncated.
 // decode(encode(x)) <= x for every x >= 0; code 0 decodes to 0.
@@ -115,6 +117,8 @@ struct ds_index {
     ds::DeviceBuffer<unsigned long long> phase;  // diagnostic phase timers (DS_PHASE_TIMERS=1)
     hipStream_t stream = nullptr;          // used by the host-pointer entry points
     int compute_units = 256;
+    int slow_slots = 16;
+    hipEvent_t event_begin = nullptr, event_fast = nullptr, event_dense = nullptr;  // per-kernel timing of the last call
     bool attributes_set = false;
     int64_t last_queries = 0;
 };

@@ -1111,10 +1111,13 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
 
     const int grid = static_cast<int>(std::min<int64_t>(Q, index->compute_units));
     DS_HIP(hipMemsetAsync(index->control.ptr, 0, kControlWords * sizeof(int32_t), stream));
+    DS_HIP(hipEventRecord(index->event_begin, stream));
     hipLaunchKernelGGL(ds_jaccard_topk_kernel, dim3(grid), dim3(kThreads), kFastLdsBytes, stream, args);
     DS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(ds_jaccard_dense_kernel, dim3(kSlowSlots), dim3(kThreads), kDenseLdsBytes, stream, args);
+    DS_HIP(hipEventRecord(index->event_fast, stream));
+    hipLaunchKernelGGL(ds_jaccard_dense_kernel, dim3(index->slow_slots), dim3(kThreads), kDenseLdsBytes, stream, args);
     DS_HIP(hipGetLastError());
+    DS_HIP(hipEventRecord(index->event_dense, stream));
     return DS_OK;
 }
 
@@ -1145,7 +1148,15 @@ static int collect(ds_index *index, hipStream_t stream, int64_t stats[32])
         stats[23] = control[kCtlRawEntries];
         stats[24] = control[kCtlSurvivors];
         stats[25] = control[kCtlRawSparse];
-        for (int i = 26; i < 32; ++i) stats[i] = 0;
+        float fast_ms = 0.f, dense_ms = 0.f;
+        if (index->last_queries > 0 && hipEventElapsedTime(&fast_ms, index->event_begin, index->event_fast) == hipSuccess &&
+            hipEventElapsedTime(&dense_ms, index->event_fast, index->event_dense) == hipSuccess) {
+            stats[26] = static_cast<int64_t>(fast_ms * 1000.f);
+            stats[27] = static_cast<int64_t>(dense_ms * 1000.f);
+        } else {
+            stats[26] = stats[27] = 0;
+        }
+        for (int i = 28; i < 32; ++i) stats[i] = 0;
     }
     if (control[kCtlErrors] != 0 && index->last_queries > 0) {
         std::vector<int32_t> status(static_cast<size_t>(index->last_queries));

@@ -170,10 +170,15 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     if (status == DS_OK) status = index->tile_sums_min.upload(tile_sums_min.data(), tile_sums_min.size());
     if (status == DS_OK) status = index->signature.upload(signature.data(), signature.size());
     if (status == DS_OK) status = index->sig_column.upload(sig_column.data(), sig_column.size());
-    if (status == DS_OK) status = index->slow_scratch.allocate(static_cast<size_t>(ds::kSlowSlots) * N);
+    index->slow_slots = static_cast<int>(std::max<int64_t>(
+        ds::kSlowSlotsMin, std::min<int64_t>(ds::kSlowSlotsMax, ds::kSlowScratchBytes / (8 * N))));
+    if (status == DS_OK) status = index->slow_scratch.allocate(static_cast<size_t>(index->slow_slots) * N);
     if (status == DS_OK) status = index->control.allocate(ds::kControlWords);
-    if (status == DS_OK && hipStreamCreate(&index->stream) != hipSuccess) {
-        ds::set_error("ds_index_create: hipStreamCreate failed");
+    if (status == DS_OK && (hipStreamCreate(&index->stream) != hipSuccess ||
+                            hipEventCreate(&index->event_begin) != hipSuccess ||
+                            hipEventCreate(&index->event_fast) != hipSuccess ||
+                            hipEventCreate(&index->event_dense) != hipSuccess)) {
+        ds::set_error("ds_index_create: hipStreamCreate / hipEventCreate failed");
         status = DS_E_HIP;
     }
     if (status != DS_OK) {
@@ -189,6 +194,9 @@ void ds_index_destroy(ds_index *index)
     if (!index) return;
     (void)hipSetDevice(index->device);
     if (index->stream) (void)hipStreamDestroy(index->stream);
+    if (index->event_begin) (void)hipEventDestroy(index->event_begin);
+    if (index->event_fast) (void)hipEventDestroy(index->event_fast);
+    if (index->event_dense) (void)hipEventDestroy(index->event_dense);
     delete index;
 }
 

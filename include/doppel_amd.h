@@ -74,7 +74,10 @@ int ds_jaccard_topk_device(ds_index *index, const int64_t *d_q_rowptr, const int
  * (setup, list pointers, scatter, scan, select, exact stage, dense hand-over; only with DS_PHASE_TIMERS=1),
  * stats[12]=tiles handled sparsely, stats[13]=tiles scanned densely, stats[14]=skipped (non-essential) columns
  * summed over queries, stats[16..21]=queries handed to the dense kernel by reason (unsupported shape, work items,
- * candidate overflow in a sparse tile, in a dense tile, ties after pruning, fewer than k positive rows). */
+ * candidate overflow in a sparse tile, in a dense tile, ties after pruning, fewer than k positive rows),
+ * stats[22..25]=refine passes / raw entries / survivors / raw entries from sparse tiles (diagnostics),
+ * stats[26]=duration of ds_jaccard_topk_kernel in microseconds (HIP events on the launch stream),
+ * stats[27]=duration of ds_jaccard_dense_kernel in microseconds. */
 int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[32]);
 
 /* ---- Levenshtein / features:  fast_levenshtein_ratio + construct_features (feature_engineering.py:25-169) ------- */
