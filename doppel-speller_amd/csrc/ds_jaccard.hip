@@ -89,7 +89,7 @@ constexpr int kOffCtrl = kOffHist + 256 * 4;
 constexpr int kFastLdsBytes = kOffCtrl + 128;
 static_assert(kFastLdsBytes <= 160 * 1024, "LDS budget of one CU exceeded");
 static_assert(kMaxQueryColumns == 128 && kItemQuads == 256, "item encoding: 7 bits column, 5 bits chunk");
-constexpr int kRefineBatch = 256;  // raw entries that make a refine pass worth its three barriers
+constexpr int kRefineBatch = 128;  // raw entries that make a refine pass worth its three barriers
 constexpr int kRefineRoom = 640;   // refine when fewer free candidate slots than this remain
 constexpr int kKeep = (kCandidates + kThreads - 1) / kThreads;  // candidate entries a thread holds while compacting
 constexpr int kSelectTrigger = kCandidates - kLooseStep;
@@ -1101,7 +1101,7 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     args.n_queries = Q;
     args.n_tiles = static_cast<int32_t>(index->n_tiles);
     args.k = k;
-    args.sparse_quads = 4096;
+    args.sparse_quads = 1024;  // measured: 512..1024 is the flat optimum on C2 (profiles/r01_d_tuning.txt)
     if (const char *limit = getenv("DS_SPARSE_QUADS"); limit != nullptr) args.sparse_quads = atoi(limit);
     args.sums_min = index->sums_min;
     args.debug = 0;
