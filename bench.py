@@ -88,7 +88,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
-    distributed = world > 1
+    # DS_BENCH_FORCE_DIST=1 exercises the torch.distributed / RCCL plumbing with a single rank (1-GPU rehearsal)
+    distributed = world > 1 or os.environ.get("DS_BENCH_FORCE_DIST") == "1"
 
     import doppel_speller_amd as ds
     from doppel_speller_amd import _lib, synth
@@ -100,7 +101,9 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # ---- synthetic workload: truth replicated (same seed), queries distinct per rank
     t0 = time.perf_counter()

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
         bool tight = false;
         int next_select = max(4 * k, 64);
         if (next_select > kSelectTrigger) next_select = kSelectTrigger;
-        int selects = 0, sparse_tiles = 0, dense_tiles = 0;
+        int selects = 0, sparse_tiles = 0, dense_tiles = 0, last_appended = 0;
         DS_STAMP(0);
 
         // `refine` turns the RAW entries (approximate essential score, row) appended by the sweeps into candidates:
@@ -643,12 +643,23 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             int r0 = sparse ? limit : 0;
             if (!sparse) ++dense_tiles;
             bool select_now = sparse && first_raw == ctrl[kLCount] && ctrl[kLCount] >= next_select;
+            int retries = 0;
+            int32_t drop_lo = 0, drop_hi = 0;  // rows to drop at the next pruning (a step that is scanned again)
             while (r0 < limit || select_now) {
+                bool force_select = false;
                 if (r0 < limit) {
+                    // no running value yet: 512-row steps; afterwards the whole rest of the tile.  The scores of a step
+                    // are zeroed only once the step has fitted into the candidate buffer: if a flood of rows above a
+                    // still weak threshold overflows it, the step is undone, the threshold is tightened from what is
+                    // already buffered, and the same rows are scanned again.
                     const int r1 = tight ? limit : min(r0 + kLooseStep, limit);
+                    // a flood is only to be expected while the threshold is young or the last step appended a lot;
+                    // otherwise zero on the fly (one LDS pass and one barrier less) and treat an overflow as fatal
+                    const bool recoverable = tight && (selects <= 2 || last_appended > 128);
+                    const int count_at_step = ctrl[kLCount];
                     for (int idx = r0 + tid * 4; idx < r1; idx += kThreads * 4) {
                         const uint4 raw4 = *reinterpret_cast<uint4 *>(&iscores[idx]);
-                        *reinterpret_cast<uint4 *>(&iscores[idx]) = make_uint4(0u, 0u, 0u, 0u);
+                        if (!recoverable) *reinterpret_cast<uint4 *>(&iscores[idx]) = make_uint4(0u, 0u, 0u, 0u);
                         const float4 s4 = make_float4(static_cast<float>(raw4.x) * from_fixed,
                                                       static_cast<float>(raw4.y) * from_fixed,
                                                       static_cast<float>(raw4.z) * from_fixed,
@@ -667,14 +678,40 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                         consider4(sv, rows4, bound4, mass4);
                     }
                     __syncthreads();
-                    r0 = r1;
-                    if (ctrl[kLOverflow]) { slow = true; reason = 3; break; }
-                    if (!tight || refine_due()) refine();
+                    last_appended = ctrl[kLCount] - count_at_step;
+                    if (ctrl[kLOverflow]) {
+                        // the buffer holds as many of the step's rows as fitted: refine them, tighten the threshold
+                        // with them, drop the step's rows from the buffer and scan the same rows again
+                        if (!recoverable || ++retries > 4) { slow = true; reason = 3; break; }
+                        __syncthreads();
+                        if (tid == 0) {
+                            ctrl[kLCount] = kCandidates;
+                            ctrl[kLOverflow] = 0;
+                        }
+                        __syncthreads();
+                        refine();
+                        force_select = true;
+                        drop_lo = static_cast<int32_t>(tile_base + r0);
+                        drop_hi = static_cast<int32_t>(tile_base + r1);
+                    } else {
+                        if (recoverable) {
+                            for (int idx = r0 + tid * 4; idx < r1; idx += kThreads * 4)
+                                *reinterpret_cast<uint4 *>(&iscores[idx]) = make_uint4(0u, 0u, 0u, 0u);
+                            __syncthreads();
+                        }
+                        r0 = r1;
+                        retries = 0;
+                        if (!tight || refine_due()) refine();
+                    }
                     DS_STAMP(3);
                 }
                 select_now = false;
                 const int m = ctrl[kLCount];
-                if (m < next_select || first_raw != m) continue;  // raw entries are refined before any selection
+                // raw entries are refined before any selection
+                if ((m < next_select && !force_select) || first_raw != m || m < k) {
+                    if (force_select) { slow = true; reason = 3; break; }  // nothing to tighten with
+                    continue;
+                }
                 // ---- tighten: tau = k-th largest lower estimate seen so far; keep what can still qualify
                 const uint32_t tau_key = radix_select_kth(cand_key, m, k, hist, ctrl);
                 ++selects;
@@ -762,12 +799,14 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                 __syncthreads();
 #pragma unroll
                 for (int r = 0; r < kKeep; ++r) {
-                    if (keep_row[r] >= 0 && __uint_as_float(keep_key[r]) >= cut) {
+                    if (keep_row[r] >= 0 && __uint_as_float(keep_key[r]) >= cut &&
+                        !(keep_row[r] >= drop_lo && keep_row[r] < drop_hi)) {
                         const int slot = atomicAdd(const_cast<int32_t *>(&ctrl[kLCount]), 1);
                         cand_key[slot] = keep_key[r];
                         cand_row[slot] = keep_row[r];
                     }
                 }
+                drop_lo = drop_hi = 0;
                 __syncthreads();
                 const int kept = ctrl[kLCount];
                 if (kept > kSelectTrigger) { slow = true; reason = 4; break; }  // massive ties: use the dense kernel
