@@ -14,6 +14,6 @@ from . import _lib  # noqa: F401
 from ._lib import DoppelError, build_library, library_path  # noqa: F401
 from .feature_engineering import (  # noqa: F401
     FEATURES_COUNT, TitleTable, construct_features, construct_features_indexed, encode_title, encode_titles,
-    get_truth_words_counts, levenshtein_ratio_batch, ALLOWED_CHARACTERS, SPACE_CODE)
+    get_truth_words_counts, levenshtein_ratio_batch, find_close_matches, ALLOWED_CHARACTERS, SPACE_CODE, SORT_KEY)
 from .match_maker import MatchMaker, TruthIndex  # noqa: F401
 from .pipeline import CandidatePipeline  # noqa: F401

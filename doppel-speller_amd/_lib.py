@@ -54,6 +54,8 @@ def _declare(handle):
         "ds_construct_features_indexed_device": [p, p, p, p, c.c_int64, c.c_int32, c.c_uint8, c.c_uint32, c.c_int64,
                                                  p, p],
         "ds_levenshtein_ratio_batch": [p, p, p, p, c.c_int64, c.c_int, c.c_int, p],
+        "ds_close_matches": [p, p, p, c.c_int32, c.c_int64, c.c_uint8, p, c.c_int32, p, p],
+        "ds_close_matches_device": [p, p, p, c.c_int64, c.c_int32, c.c_int64, c.c_uint8, p, c.c_int32, p, p, p],
         "ds_malloc": [c.POINTER(p), c.c_size_t, c.c_int],
         "ds_free": [p, c.c_int],
         "ds_memcpy_h2d": [p, p, c.c_size_t, c.c_int],
@@ -80,7 +82,7 @@ EXPORTED_SYMBOLS = (
     "ds_last_error", "ds_version", "ds_device_count", "ds_device_name", "ds_index_create", "ds_index_destroy",
     "ds_index_info", "ds_jaccard_topk", "ds_jaccard_topk_device", "ds_jaccard_sync", "ds_construct_features",
     "ds_titles_create", "ds_titles_destroy", "ds_construct_features_indexed", "ds_construct_features_indexed_device",
-    "ds_levenshtein_ratio_batch", "ds_malloc", "ds_free", "ds_memcpy_h2d", "ds_memcpy_d2h", "ds_memset",
+    "ds_levenshtein_ratio_batch", "ds_close_matches", "ds_close_matches_device", "ds_malloc", "ds_free", "ds_memcpy_h2d", "ds_memcpy_d2h", "ds_memset",
     "ds_stream_sync", "ds_timer_create", "ds_timer_destroy", "ds_timer_start", "ds_timer_stop",
     "ds_timer_elapsed_ms")
 

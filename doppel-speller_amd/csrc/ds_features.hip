@@ -51,6 +51,8 @@ struct WaveScratch {
     float features[72];
     int32_t word_begin[16];
     int32_t word_len[16];
+    uint8_t token_begin[128];  // token-sort scratch of the close-match kernel
+    uint8_t token_len[128];
 };
 
 __device__ __forceinline__ uint8_t ratio_from_lcs(int lcs, int total_length)
@@ -341,6 +343,169 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_levenshtein_kernel(LevArgs
     }
 }
 
+// ---- next row f-1: Prediction._find_close_matches (doppelspeller/predict.py:140-183) ---------------------------------
+// ratio(x, y) = int(round(python-Levenshtein ratio * 100)) (common.py:161-162) behind a length pre-filter and a
+// token-sort fallback (predict.py:147-156, common.py:165-167).  python-Levenshtein is a third-party C extension that is
+// not part of the reference tree: its published definition (ratio = (lensum - ldist)/lensum, substitution cost 2,
+// i.e. 2*LCS/lensum) is restated; parity is pinned against the CPU restatement used by the tests only.
+
+// True LCS length of two LDS strings (no uint8 wrap-around semantics here): bit-parallel when the shorter string
+// fits 64 bits and the alphabet is small, else an anti-diagonal DP with three uint8 diagonals (LCS <= 255).
+__device__ int lcs_wave(WaveScratch &w, const uint8_t *a, int la, const uint8_t *b, int lb, int lane)
+{
+    if (la > lb) {
+        const uint8_t *ts = a; a = b; b = ts;
+        const int tl = la; la = lb; lb = tl;
+    }
+    if (la == 0) return 0;
+    if (la <= 64 && codes_below_64(a, la, lane) && codes_below_64(b, lb, lane)) {
+        build_masks(w, a, la, lane);
+        return lcs_bitparallel(w, b, lb, la);
+    }
+    for (int d = 0; d <= la + lb; ++d) {
+        uint8_t *current = w.diag[d % 3];
+        const uint8_t *previous = w.diag[(d + 2) % 3];
+        const uint8_t *before = w.diag[(d + 1) % 3];
+        const int x_low = d > lb ? d - lb : 0;
+        const int x_high = d < la ? d : la;
+        for (int x = x_low + lane; x <= x_high; x += 64) {
+            const int y = d - x;
+            int value = 0;
+            if (x > 0 && y > 0)
+                value = a[x - 1] == b[y - 1] ? before[x - 1] + 1 : max(previous[x - 1], previous[x]);
+            current[x] = static_cast<uint8_t>(value);
+        }
+        wave_sync();
+    }
+    return w.diag[(la + lb) % 3][la];
+}
+
+__device__ __forceinline__ int rounded_ratio(int lcs, int total)  // common.py:162  int(round(ratio * 100))
+{
+    if (total == 0) return 100;
+    return __double2int_rn((static_cast<double>(2 * lcs) / static_cast<double>(total)) * 100.0);
+}
+
+// ' '.join(sorted(text.split())) (common.py:166) of an LDS string into `out`; returns the new length.
+__device__ int token_sort_wave(WaveScratch &w, const uint8_t *text, int n, uint8_t space, const uint8_t *sort_key,
+                               uint8_t *out, int lane)
+{
+    // word starts and lengths (up to 128 words in 255 characters)
+    int words = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool starts = i < n && text[i] != space && (i == 0 || text[i - 1] == space);
+        const unsigned long long votes = __ballot(starts);
+        if (starts) {
+            int length = 1;
+            while (i + length < n && text[i + length] != space) ++length;
+            const int slot = words + __popcll(votes & ((1ull << lane) - 1ull));
+            w.token_begin[slot] = static_cast<uint8_t>(i);
+            w.token_len[slot] = static_cast<uint8_t>(length);
+        }
+        words += __popcll(votes);
+    }
+    wave_sync();
+    int total = 0;
+    for (int base = 0; base < words; base += 64) {  // lane = word; rank by counting the words that sort before it
+        const int i = base + lane;
+        int offset = 0, rank = 0, my_begin = 0, my_length = 0;
+        if (i < words) {
+            my_begin = w.token_begin[i];
+            my_length = w.token_len[i];
+            for (int j = 0; j < words; ++j) {
+                if (j == i) continue;
+                const int begin = w.token_begin[j], length = w.token_len[j];
+                const int common = min(length, my_length);
+                int compare = 0;
+                for (int c = 0; c < common && compare == 0; ++c)
+                    compare = static_cast<int>(sort_key[text[begin + c]]) - static_cast<int>(sort_key[text[my_begin + c]]);
+                if (compare == 0) compare = length - my_length;
+                if (compare < 0 || (compare == 0 && j < i)) {  // word j comes first (stable)
+                    offset += length + 1;
+                    ++rank;
+                }
+            }
+            if (rank > 0) out[offset - 1] = space;
+            for (int c = 0; c < my_length; ++c) out[offset + c] = text[my_begin + c];
+        }
+        (void)rank;
+    }
+    for (int j = 0; j < words; ++j) total += w.token_len[j] + 1;
+    wave_sync();
+    return total > 0 ? total - 1 : 0;
+}
+
+struct CloseArgs {
+    const uint8_t *q_enc;
+    const uint8_t *q_len;
+    const uint8_t *t_enc;
+    const uint8_t *t_len;
+    const int32_t *pair_q;  // nullable
+    const int32_t *pair_t;
+    const uint8_t *sort_key;  // [256] code -> character order of Python's sorted()
+    uint8_t *ratios;          // [n]
+    int32_t *best_row;        // [n / k] or null
+    int64_t q_stride, t_stride, n_q, n_t, n, q_first;
+    int32_t k;
+    int32_t threshold;
+    uint8_t space_code;
+};
+
+// Prediction._get_levenshtein_ratio (predict.py:147-156) for every pair; one wavefront per pair.
+__global__ __launch_bounds__(kFeatWaves * 64) void ds_close_ratio_kernel(CloseArgs a)
+{
+    __shared__ WaveScratch scratch[kFeatWaves];
+    __shared__ uint8_t sort_key[256];
+    sort_key[threadIdx.x] = a.sort_key[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    WaveScratch &w = scratch[threadIdx.x >> 6];
+    const int64_t wave_global = static_cast<int64_t>(blockIdx.x) * kFeatWaves + (threadIdx.x >> 6);
+    const int64_t wave_count = static_cast<int64_t>(gridDim.x) * kFeatWaves;
+    for (int64_t pair = wave_global; pair < a.n; pair += wave_count) {
+        const int64_t qi = a.pair_q ? a.pair_q[pair] : (a.k > 0 ? a.q_first + pair / a.k : pair);
+        const int64_t ti = a.pair_t[pair];
+        int ratio = 0;
+        if (qi >= 0 && qi < a.n_q && ti >= 0 && ti < a.n_t) {
+            const int lx = a.q_len[qi], ly = a.t_len[ti];
+            const int total = lx + ly, delta = lx > ly ? lx - ly : ly - lx;
+            // predict.py:141-151 length pre-filter, float64 in source order
+            const bool may_match =
+                total > 0 && !((static_cast<double>(total - delta) / static_cast<double>(total)) * 100.0 <
+                               static_cast<double>(a.threshold));
+            if (may_match) {
+                wave_sync();
+                for (int i = lane; i < lx; i += 64) w.q[i] = a.q_enc[qi * a.q_stride + i];
+                for (int i = lane; i < ly; i += 64) w.t[i] = a.t_enc[ti * a.t_stride + i];
+                wave_sync();
+                ratio = rounded_ratio(lcs_wave(w, w.q, lx, w.t, ly, lane), total);               // predict.py:153
+                if (ratio <= a.threshold) {                                                          // :154-155
+                    const int sx = token_sort_wave(w, w.q, lx, a.space_code, sort_key, w.recon, lane);
+                    const int sy = token_sort_wave(w, w.t, ly, a.space_code, sort_key, w.qw, lane);
+                    ratio = rounded_ratio(lcs_wave(w, w.recon, sx, w.qw, sy, lane), sx + sy);
+                }
+            }
+        }
+        if (lane == 0) a.ratios[pair] = static_cast<uint8_t>(ratio);
+    }
+}
+
+// predict.py:172-176: per query the candidates with ratio > threshold, the maximum among them, and the query is
+// matched only when exactly one candidate reaches it (_remove_duplicated_matches drops the others).
+__global__ void ds_close_best_kernel(CloseArgs a)
+{
+    const int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (q >= a.n / a.k) return;
+    int best = a.threshold, count = 0, where = -1;
+    for (int j = 0; j < a.k; ++j) {
+        const int ratio = a.ratios[q * a.k + j];
+        if (ratio > best) { best = ratio; count = 1; where = j; }
+        else if (ratio == best && where >= 0) ++count;
+    }
+    a.best_row[q] = (where >= 0 && count == 1) ? a.pair_t[q * a.k + where] : -1;
+}
+
 static int launch_features(const FeatureArgs &args, int device, hipStream_t stream)
 {
     if (args.n == 0) return DS_OK;
@@ -497,6 +662,61 @@ int ds_levenshtein_ratio_batch(const uint8_t *a_chars, const int64_t *a_off, con
     hipLaunchKernelGGL(ds::ds_levenshtein_kernel, dim3(grid), dim3(ds::kFeatWaves * 64), 0, nullptr, args);
     DS_HIP(hipGetLastError());
     DS_HIP(hipMemcpy(out, d_out.ptr, static_cast<size_t>(n), hipMemcpyDeviceToHost));
+    return DS_OK;
+}
+
+int ds_close_matches_device(ds_titles *queries, ds_titles *truth, const int32_t *d_pair_t, int64_t q_first, int32_t k,
+                            int64_t n_queries, uint8_t space_code, const uint8_t *d_sort_key, int32_t threshold,
+                            uint8_t *d_ratios, int32_t *d_best_row, void *stream)
+{
+    DS_REQUIRE(queries && truth, "ds_close_matches: null table");
+    DS_REQUIRE(queries->device == truth->device, "ds_close_matches: tables on different devices");
+    DS_REQUIRE(k >= 1 && n_queries >= 0, "ds_close_matches: bad k / query count");
+    if (n_queries == 0) return DS_OK;
+    DS_REQUIRE(d_pair_t && d_sort_key && d_ratios, "ds_close_matches: null pointer");
+    DS_HIP(hipSetDevice(truth->device));
+    ds::CloseArgs args{};
+    args.q_enc = queries->enc.ptr; args.q_len = queries->len.ptr; args.t_enc = truth->enc.ptr;
+    args.t_len = truth->len.ptr; args.pair_q = nullptr; args.pair_t = d_pair_t; args.sort_key = d_sort_key;
+    args.ratios = d_ratios; args.best_row = d_best_row; args.q_stride = queries->stride;
+    args.t_stride = truth->stride; args.n_q = queries->n; args.n_t = truth->n; args.n = n_queries * k;
+    args.q_first = q_first; args.k = k; args.threshold = threshold; args.space_code = space_code;
+    const int64_t blocks_needed = (args.n + ds::kFeatWaves - 1) / ds::kFeatWaves;
+    const int grid = static_cast<int>(std::min<int64_t>(blocks_needed, 256 * 32));
+    hipLaunchKernelGGL(ds::ds_close_ratio_kernel, dim3(grid), dim3(ds::kFeatWaves * 64), 0,
+                       static_cast<hipStream_t>(stream), args);
+    DS_HIP(hipGetLastError());
+    if (d_best_row) {
+        hipLaunchKernelGGL(ds::ds_close_best_kernel, dim3(static_cast<unsigned>((n_queries + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), args);
+        DS_HIP(hipGetLastError());
+    }
+    return DS_OK;
+}
+
+int ds_close_matches(ds_titles *queries, ds_titles *truth, const int32_t *pair_t, int32_t k, int64_t n_queries,
+                     uint8_t space_code, const uint8_t *sort_key, int32_t threshold, uint8_t *ratios,
+                     int32_t *best_row)
+{
+    DS_REQUIRE(queries && truth, "ds_close_matches: null table");
+    DS_REQUIRE(k >= 1 && n_queries >= 0, "ds_close_matches: bad k / query count");
+    if (n_queries == 0) return DS_OK;
+    DS_REQUIRE(pair_t && sort_key && ratios && best_row, "ds_close_matches: null pointer");
+    DS_REQUIRE(n_queries <= queries->n, "ds_close_matches: more queries than rows in the query table");
+    DS_HIP(hipSetDevice(truth->device));
+    const size_t n = static_cast<size_t>(n_queries) * static_cast<size_t>(k);
+    ds::DeviceBuffer<int32_t> d_t, d_best;
+    ds::DeviceBuffer<uint8_t> d_key, d_ratios;
+    int status = d_t.upload(pair_t, n);
+    if (status == DS_OK) status = d_key.upload(sort_key, 256);
+    if (status == DS_OK) status = d_ratios.allocate(n);
+    if (status == DS_OK) status = d_best.allocate(static_cast<size_t>(n_queries));
+    if (status != DS_OK) return status;
+    status = ds_close_matches_device(queries, truth, d_t.ptr, 0, k, n_queries, space_code, d_key.ptr, threshold,
+                                     d_ratios.ptr, d_best.ptr, nullptr);
+    if (status != DS_OK) return status;
+    DS_HIP(hipMemcpy(ratios, d_ratios.ptr, n, hipMemcpyDeviceToHost));
+    DS_HIP(hipMemcpy(best_row, d_best.ptr, static_cast<size_t>(n_queries) * sizeof(int32_t), hipMemcpyDeviceToHost));
     return DS_OK;
 }
 

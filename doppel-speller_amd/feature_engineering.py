@@ -155,3 +155,30 @@ def levenshtein_ratio_batch(a_sequences, b_sequences, method=0, device=0):
         _lib.pointer(a_chars), _lib.pointer(a_off), _lib.pointer(b_chars), _lib.pointer(b_off), len(a_sequences),
         method, device, _lib.pointer(out)), "ds_levenshtein_ratio_batch")
     return out
+
+
+LEVENSHTEIN_RATIO_THRESHOLD = 94                               # settings.py:75
+# order of the character codes under Python's sorted() (common.py:166): the code point of the character
+SORT_KEY = np.zeros(256, dtype=np.uint8)
+for _character, _code in _ENCODING.items():
+    SORT_KEY[_code] = ord(_character)
+
+
+def find_close_matches(queries, truth, rows, threshold=LEVENSHTEIN_RATIO_THRESHOLD, space_code=SPACE_CODE,
+                       sort_key=SORT_KEY):
+    """The fuzzy step of Prediction._find_close_matches (predict.py:140-183) for the first len(rows) queries.
+
+    queries / truth: TitleTables; rows: int32[Q, k] candidate truth rows per query (the Jaccard top-k).
+    Returns (ratios uint8[Q, k], best_row int32[Q]): ratios[q, j] = Prediction._get_levenshtein_ratio(query q,
+    candidate j) (predict.py:147-156); best_row[q] = the single candidate with the highest ratio above `threshold`
+    (predict.py:172-176), -1 when none or when several tie (_remove_duplicated_matches, predict.py:158-161).
+    """
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    n_queries, k = rows.shape
+    ratios = np.empty((n_queries, k), dtype=np.uint8)
+    best_row = np.empty(n_queries, dtype=np.int32)
+    sort_key = np.ascontiguousarray(sort_key, dtype=np.uint8)
+    _lib.check(_lib.lib().ds_close_matches(queries.handle, truth.handle, _lib.pointer(rows), k, n_queries,
+                                           int(space_code), _lib.pointer(sort_key), int(threshold),
+                                           _lib.pointer(ratios), _lib.pointer(best_row)), "ds_close_matches")
+    return ratios, best_row

@@ -107,6 +107,21 @@ int ds_construct_features_indexed_device(ds_titles *queries, ds_titles *truth, c
 int ds_levenshtein_ratio_batch(const uint8_t *a_chars, const int64_t *a_off, const uint8_t *b_chars,
                                const int64_t *b_off, int64_t n, int method, int device, uint8_t *out);
 
+/* ---- next row: Prediction._find_close_matches (predict.py:140-183) -------------------------------- */
+/* For query row q (q_first + q in the query table) and its k candidate truth rows pair_t[q*k .. q*k+k):
+ * ratios[q*k+j] = Prediction._get_levenshtein_ratio(query, candidate) (predict.py:147-156: length pre-filter,
+ * common.levenshtein_ratio = int(round(python-Levenshtein ratio * 100)), token-sort fallback common.py:165-167);
+ * best_row[q] = the candidate with the highest ratio > threshold if exactly one reaches it (predict.py:172-176), else
+ * -1.  sort_key[256] = order of the character codes under Python's sorted() (the code points).  python-Levenshtein is
+ * not part of the reference tree: its published definition is restated (parity pinned against the tests' CPU
+ * restatement only). */
+int ds_close_matches(ds_titles *queries, ds_titles *truth, const int32_t *pair_t, int32_t k, int64_t n_queries,
+                     uint8_t space_code, const uint8_t *sort_key, int32_t threshold, uint8_t *ratios,
+                     int32_t *best_row);
+int ds_close_matches_device(ds_titles *queries, ds_titles *truth, const int32_t *d_pair_t, int64_t q_first, int32_t k,
+                            int64_t n_queries, uint8_t space_code, const uint8_t *d_sort_key, int32_t threshold,
+                            uint8_t *d_ratios, int32_t *d_best_row, void *stream);
+
 /* ---- device memory / stream / timing plumbing (so tests and bench.py can keep inputs resident in HBM) ----------- */
 int ds_malloc(void **ptr, size_t bytes, int device);
 int ds_free(void *ptr, int device);

@@ -300,3 +300,101 @@ int64_t ds_oracle_feature_cells(uint8_t lq8, uint8_t lt8, const uint8_t *title, 
     }
     return cells + (reconstructed > 1 ? reconstructed - 1 : 0) * lt;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Next row f-1: the fuzzy "very close match" step of Prediction._find_close_matches
+ * (doppelspeller/predict.py:140-183) on top of common.levenshtein_ratio / levenshtein_token_sort_ratio
+ * (doppelspeller/common.py:161-167).  The latter call python-Levenshtein 0.12.0 `ratio`, which is NOT under
+ * /root/reference (requirements.txt:9) and not installed here: PARITY UNPINNED.  Restated from its published
+ * algorithm: ratio(a, b) = (lensum - ldist) / lensum with ldist the edit distance with substitution cost 2
+ * (= lensum - 2*LCS), 1.0 for two empty strings; common.py:162 then takes int(round(ratio * 100)) (round half to even).
+ * Strings are code arrays; `sort_key[code]` gives the character order Python's sorted() uses (the code point).
+ * ------------------------------------------------------------------------------------------------------------------ */
+static int64_t lcs_length(const uint8_t *a, int64_t la, const uint8_t *b, int64_t lb)
+{
+    int32_t *row = (int32_t *)calloc((size_t)lb + 1, sizeof(int32_t));
+    for (int64_t i = 1; i <= la; ++i) {
+        int32_t diagonal = 0;
+        for (int64_t j = 1; j <= lb; ++j) {
+            const int32_t up = row[j];
+            row[j] = a[i - 1] == b[j - 1] ? diagonal + 1 : (row[j - 1] > up ? row[j - 1] : up);
+            diagonal = up;
+        }
+    }
+    const int64_t result = row[lb];
+    free(row);
+    return result;
+}
+
+/* common.py:161-162 */
+int32_t ds_oracle_levenshtein_ratio_rounded(const uint8_t *a, int32_t la, const uint8_t *b, int32_t lb)
+{
+    const int64_t lensum = (int64_t)la + lb;
+    if (lensum == 0) return 100;
+    const int64_t ldist = lensum - 2 * lcs_length(a, la, b, lb);
+    const double ratio = (double)(lensum - ldist) / (double)lensum;
+    return (int32_t)nearbyint(ratio * 100);
+}
+
+/* ' '.join(sorted(text.split())) of common.py:166 on a code string; returns the new length (<= n) */
+static int64_t token_sort(const uint8_t *text, int64_t n, uint8_t space, const uint8_t *sort_key, uint8_t *out)
+{
+    int64_t starts[256], lengths[256], words = 0;
+    for (int64_t i = 0; i < n;) {
+        while (i < n && text[i] == space) ++i;
+        if (i >= n) break;
+        const int64_t start = i;
+        while (i < n && text[i] != space) ++i;
+        starts[words] = start;
+        lengths[words++] = i - start;
+    }
+    for (int64_t i = 1; i < words; ++i) { /* stable insertion sort, lexicographic on sort_key */
+        const int64_t s = starts[i], l = lengths[i];
+        int64_t j = i - 1;
+        for (; j >= 0; --j) {
+            const int64_t m = lengths[j] < l ? lengths[j] : l;
+            int cmp = 0;
+            for (int64_t c = 0; c < m && cmp == 0; ++c)
+                cmp = (int)sort_key[text[starts[j] + c]] - (int)sort_key[text[s + c]];
+            if (cmp == 0) cmp = lengths[j] > l ? 1 : 0;
+            if (cmp <= 0) break;
+            starts[j + 1] = starts[j];
+            lengths[j + 1] = lengths[j];
+        }
+        starts[j + 1] = s;
+        lengths[j + 1] = l;
+    }
+    int64_t at = 0;
+    for (int64_t w = 0; w < words; ++w) {
+        if (w) out[at++] = space;
+        memcpy(out + at, text + starts[w], (size_t)lengths[w]);
+        at += lengths[w];
+    }
+    return at;
+}
+
+/* Prediction._get_levenshtein_ratio (predict.py:140-156) */
+int32_t ds_oracle_close_ratio(const uint8_t *x, int32_t lx, const uint8_t *y, int32_t ly, uint8_t space,
+                              const uint8_t *sort_key, int32_t threshold)
+{
+    const int64_t total = (int64_t)lx + ly;
+    const int64_t delta = lx > ly ? lx - ly : ly - lx;
+    if (((double)(total - delta) / (double)total) * 100 < (double)threshold) return 0;      /* :141-151 */
+    const int32_t ratio = ds_oracle_levenshtein_ratio_rounded(x, lx, y, ly);                /* :153 */
+    if (ratio > threshold) return ratio;
+    uint8_t sorted_x[256], sorted_y[256];                                                   /* :154-155 */
+    const int64_t sx = token_sort(x, lx, space, sort_key, sorted_x);
+    const int64_t sy = token_sort(y, ly, space, sort_key, sorted_y);
+    return ds_oracle_levenshtein_ratio_rounded(sorted_x, (int32_t)sx, sorted_y, (int32_t)sy);
+}
+
+/* ratios for n pairs given as padded rows (stride bytes apart) */
+void ds_oracle_close_ratios(const uint8_t *x_len, const uint8_t *y_len, const uint8_t *x, const uint8_t *y,
+                            int64_t n, int64_t stride, uint8_t space, const uint8_t *sort_key, int32_t threshold,
+                            uint8_t *out)
+{
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < n; ++i)
+        out[i] = (uint8_t)ds_oracle_close_ratio(x + i * stride, x_len[i], y + i * stride, y_len[i], space, sort_key,
+                                                threshold);
+}

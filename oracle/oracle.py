@@ -133,3 +133,28 @@ def feature_cells(title_len, truth_len, title_enc, truth_enc, space_code):
             ctypes.c_uint8(int(title_len[i])), ctypes.c_uint8(int(truth_len[i])),
             _ptr(title_enc[i], ctypes.c_uint8), _ptr(truth_enc[i], ctypes.c_uint8), ctypes.c_uint8(int(space_code)))
     return out
+
+
+def levenshtein_ratio_rounded(a, b):
+    """common.py:161-162 (python-Levenshtein ratio, restated -- parity unpinned) on two uint8 code arrays."""
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    return int(lib().ds_oracle_levenshtein_ratio_rounded(_ptr(a, ctypes.c_uint8), ctypes.c_int32(a.shape[0]),
+                                                         _ptr(b, ctypes.c_uint8), ctypes.c_int32(b.shape[0])))
+
+
+def close_ratios(x_len, y_len, x_enc, y_enc, space_code, sort_key, threshold=94):
+    """Prediction._get_levenshtein_ratio (predict.py:140-156) for n padded pairs -> uint8[n]."""
+    x_len = np.ascontiguousarray(x_len, dtype=np.uint8)
+    y_len = np.ascontiguousarray(y_len, dtype=np.uint8)
+    x_enc = np.ascontiguousarray(x_enc, dtype=np.uint8)
+    y_enc = np.ascontiguousarray(y_enc, dtype=np.uint8)
+    sort_key = np.ascontiguousarray(sort_key, dtype=np.uint8)
+    assert sort_key.shape == (256,) and x_enc.shape == y_enc.shape
+    out = np.empty(x_len.shape[0], dtype=np.uint8)
+    lib().ds_oracle_close_ratios(_ptr(x_len, ctypes.c_uint8), _ptr(y_len, ctypes.c_uint8), _ptr(x_enc, ctypes.c_uint8),
+                                 _ptr(y_enc, ctypes.c_uint8), ctypes.c_int64(x_len.shape[0]),
+                                 ctypes.c_int64(x_enc.shape[1]), ctypes.c_uint8(int(space_code)),
+                                 _ptr(sort_key, ctypes.c_uint8), ctypes.c_int32(int(threshold)),
+                                 _ptr(out, ctypes.c_uint8))
+    return out

@@ -41,12 +41,17 @@ def test_argument_errors_without_gpu(library):
 
 
 def test_product_never_imports_the_oracle():
-    package = os.path.join(ROOT, "doppel-speller_amd")
-    for directory, _, files in os.walk(package):
-        for name in files:
-            if name.endswith((".py", ".hip", ".h", ".cpp")):
-                text = open(os.path.join(directory, name)).read()
-                assert "oracle" not in text.replace("# oracle", ""), os.path.join(directory, name)
+    """No file of the product (package sources, HIP sources, the C ABI header) imports, links or calls the oracle."""
+    forbidden = ("import oracle", "from oracle", "libdoppel_oracle", "ds_oracle_", "oracle/", "oracle.")
+    roots = [os.path.join(ROOT, "doppel-speller_amd"), os.path.join(ROOT, "doppel_speller_amd"),
+             os.path.join(ROOT, "include")]
+    for root in roots:
+        for directory, _, files in os.walk(root):
+            for name in files:
+                if name.endswith((".py", ".hip", ".h", ".cpp")):
+                    text = open(os.path.join(directory, name)).read()
+                    for needle in forbidden:
+                        assert needle not in text, (os.path.join(directory, name), needle)
 
 
 def test_encoders_known_answers(golden_kat):
