@@ -135,9 +135,13 @@ def main():
         timer_j.start(stream)
         pipeline.enqueue_top_k(stream)
         timer_j.stop(stream)
+        if os.environ.get("DS_BENCH_SYNC_EACH") == "1":  # fault localisation: which stage was running
+            log("top-k enqueued"); pipeline.sync(stream); log("top-k done")
         timer_f.start(stream)
         pipeline.enqueue_features(stream)
         timer_f.stop(stream)
+        if os.environ.get("DS_BENCH_SYNC_EACH") == "1":
+            _lib.check(_lib.lib().ds_stream_sync(None, device), "sync"); log("features done")
         if distributed:
             gather_rows(rows_tensor, args.queries * world)
         if record:
@@ -216,7 +220,7 @@ def main():
             "queries_per_s": args.queries * world / (elapsed / args.steps),
             "dense_path_queries": int(stats["dense_queries"]), "exact_candidates_per_query":
                 stats["exact_candidates"] / max(1, args.queries),
-            "verified_queries": checked, "selections_per_query": stats["selections"] / max(1, args.queries),
+            "verified_queries": checked, "bounds_record": stats.get("bounds_record"), "selections_per_query": stats["selections"] / max(1, args.queries),
             "phase_cycles": stats["phase_cycles"], "dense_reasons": stats["dense_reasons"],
             "tiles": {"sparse": stats["sparse_tiles"], "dense": stats["dense_tiles"]},
             "skipped_columns_per_query": stats["skipped_columns"] / max(1, args.queries),

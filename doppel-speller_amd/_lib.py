@@ -27,7 +27,7 @@ def build_library(force=False, verbose=False):
         if os.path.getmtime(target) >= newest:
             return target
     command = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-I", os.path.join(_ROOT, "include"), "-o", target] + sources
+               "-I", os.path.join(_ROOT, "include"), "-o", target] + os.environ.get("DS_BUILD_FLAGS", "").split() + sources
     if verbose:
         print(" ".join(command))
     subprocess.check_call(command)

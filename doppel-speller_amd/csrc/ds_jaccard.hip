@@ -57,7 +57,8 @@ struct JaccardArgs {
     int32_t k;
     int32_t sparse_quads;       // tiles with at most this many essential quads are handled sparsely
     int32_t refine_batch;       // raw entries that trigger a refine pass
-    int32_t debug;              // timing experiments only (DS_DEBUG): 1 = skip sparse sweeps, 2 = skip exchange tests
+    int32_t debug;              // timing experiments only (DS_DEBUG)
+    int64_t n_quads;            // posting quads in the index (bounds of `postings`)
     float sums_min;
 };
 
@@ -123,13 +124,16 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t value, int lane
     return value;
 }
 
-// k-th largest key of keys[0..m) (m >= k) by a 4 x 8-bit radix select.  All threads of the workgroup call it.
-__device__ uint32_t radix_select_kth(const uint32_t *keys, int m, int k, uint32_t *hist, volatile int32_t *ctrl)
+// k-th largest key of keys[0..m) (m >= k) by an 8-bit radix select.  All threads of the workgroup call it.
+// passes = 4: the exact k-th largest key; passes = 2: its upper 16 bits with the lower ones cleared, i.e. a LOWER
+// BOUND within 2^-7 relative of it -- all a running threshold needs, at half the barriers.
+__device__ uint32_t radix_select_kth(const uint32_t *keys, int m, int k, uint32_t *hist, volatile int32_t *ctrl,
+                                     int passes)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     uint32_t prefix = 0, mask = 0;
     int remaining = k;
-    for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int shift = 24; shift >= 32 - 8 * passes; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         for (int i = tid; i < m; i += kThreads) {
@@ -236,12 +240,31 @@ __device__ __forceinline__ void append_candidate(bool pass, uint32_t key, int32_
     }
 }
 
-// Diagnostic phase timers: thread 0 adds the shader-clock delta since its previous stamp to phase[slot].
+// Debug build (-DDS_BOUNDS_CHECK): every global access of the fast kernel whose index is data dependent is checked; the
+// first violation is recorded in control[24..27] (site, index low/high, limit) and the access is skipped.
+#ifdef DS_BOUNDS_CHECK
+__device__ __forceinline__ bool in_bounds(int32_t *control, int site, int64_t index, int64_t limit)
+{
+    if (index >= 0 && index < limit) return true;
+    if (atomicCAS(&control[24], 0, site) == 0) {
+        control[25] = static_cast<int32_t>(index & 0xffffffff);
+        control[26] = static_cast<int32_t>(index >> 32);
+        control[27] = static_cast<int32_t>(limit & 0x7fffffff);
+    }
+    return false;
+}
+#define DS_OK_INDEX(site, index, limit) in_bounds(a.control, site, static_cast<int64_t>(index), static_cast<int64_t>(limit))
+#else
+#define DS_OK_INDEX(site, index, limit) true
+#endif
+
+// Diagnostic phase timers: thread 0 adds the shader-clock delta since its previous stamp to an LDS accumulator
+// (flushed to HBM once, at the end of the kernel, so that stamping does not put a global atomic in front of a barrier).
 #define DS_STAMP(slot)                                                     \
     do {                                                                   \
         if (a.phase != nullptr && tid == 0) {                              \
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
-            atomicAdd(&a.phase[slot], now_ - stamp_);                      \
+            phase_lds[slot] += now_ - stamp_;                              \
             stamp_ = now_;                                                 \
         }                                                                  \
     } while (0)
@@ -249,6 +272,8 @@ __device__ __forceinline__ void append_candidate(bool pass, uint32_t key, int32_
 __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a)
 {
     unsigned long long stamp_ = a.phase != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
+    __shared__ unsigned long long phase_lds[8];
+    if (threadIdx.x < 8) phase_lds[threadIdx.x] = 0ull;
     extern __shared__ __align__(16) unsigned char lds[];
     float *scores = reinterpret_cast<float *>(lds);
     uint32_t *cand_key = reinterpret_cast<uint32_t *>(lds + kOffLo);
@@ -385,6 +410,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                 const int32_t t = i < last_raw ? cand_row[i] : -1;
                 if (t >= 0) {
                     const float raw = __uint_as_float(cand_key[i]);
+                    if (!DS_OK_INDEX(1, t, a.n_truth)) continue;
                     const float sums = a.sums32[t];
                     const uint4 signature = skipped.count > 0 ? a.signature[t] : make_uint4(0u, 0u, 0u, 0u);
                     if (may_qualify(raw, sums, bounds)) {
@@ -411,6 +437,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             __syncthreads();
             if (tid == 0 && a.phase != nullptr) atomicAdd(&a.control[kCtlSurvivors], ctrl[kLCount] - first_raw);
             first_raw = ctrl[kLCount];
+            __syncthreads();  // every thread holds the same count before anything is appended again
         };
         // refine when raw entries pile up, when a selection is due, or when the buffer runs short of room
         auto refine_due = [&]() {
@@ -425,7 +452,10 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                 const int width = min(kPtrTiles, a.n_tiles - b) + 1;
                 for (int e = tid; e < n * (kPtrTiles + 1); e += kThreads) {
                     const int j = e / (kPtrTiles + 1), i = e % (kPtrTiles + 1);
-                    ptr_cache[e] = i < width ? a.col_ptr[static_cast<int64_t>(cols[j]) * ptr_stride + b + i] : 0u;
+                    ptr_cache[e] = (i < width && DS_OK_INDEX(2, static_cast<int64_t>(cols[j]) * ptr_stride + b + i,
+                                                            a.n_columns * ptr_stride))
+                                       ? a.col_ptr[static_cast<int64_t>(cols[j]) * ptr_stride + b + i]
+                                       : 0u;
                 }
                 __syncthreads();
             }
@@ -491,6 +521,8 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             DS_STAMP(1);
 
             const int64_t tile_base = static_cast<int64_t>(b) << kTileLog2;
+            // read here, where a barrier (end of the scatter) separates every thread's read from the next append
+            int count_at_step = ctrl[kLCount];
             // row-independent gate of this tile: coef * (min sums of the tile + maxint), rounded down
             Bounds here = bounds;
             {
@@ -555,6 +587,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                         for (int u = 0; u < 4 * kUnits; ++u) {
                             const uint32_t index = first[u >> 2] + (u & 3) * 64 + lane;
                             live[u] = index < last[u >> 2];
+                            live[u] = live[u] && DS_OK_INDEX(3, index, a.n_quads);
                             quad[u] = live[u] ? quads[index] : make_uint2(0x80008000u, 0x80008000u);
                             if (sweep == 1 && live[u]) quad_sums[u] = sums_quads[index];
                         }
@@ -620,6 +653,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                         for (int u = 0; u < 4; ++u) {
                             const uint32_t index = first + u * 64;
                             live[h * 4 + u] = index < end;
+                            live[h * 4 + u] = live[h * 4 + u] && DS_OK_INDEX(4, index, a.n_quads);
                             if (live[h * 4 + u]) quad[h * 4 + u] = quads[index];
                         }
                     }
@@ -652,30 +686,46 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     // are zeroed only once the step has fitted into the candidate buffer: if a flood of rows above a
                     // still weak threshold overflows it, the step is undone, the threshold is tightened from what is
                     // already buffered, and the same rows are scanned again.
-                    const int r1 = tight ? limit : min(r0 + kLooseStep, limit);
-                    // a flood is only to be expected while the threshold is young or the last step appended a lot;
-                    // otherwise zero on the fly (one LDS pass and one barrier less) and treat an overflow as fatal
-                    const bool recoverable = tight && (selects <= 2 || last_appended > 128);
-                    const int count_at_step = ctrl[kLCount];
-                    for (int idx = r0 + tid * 4; idx < r1; idx += kThreads * 4) {
-                        const uint4 raw4 = *reinterpret_cast<uint4 *>(&iscores[idx]);
-                        if (!recoverable) *reinterpret_cast<uint4 *>(&iscores[idx]) = make_uint4(0u, 0u, 0u, 0u);
-                        const float4 s4 = make_float4(static_cast<float>(raw4.x) * from_fixed,
-                                                      static_cast<float>(raw4.y) * from_fixed,
-                                                      static_cast<float>(raw4.z) * from_fixed,
-                                                      static_cast<float>(raw4.w) * from_fixed);
-                        // mass < pre by construction, so untouched rows (score 0) never pass
-                        const bool any = s4.x + here.mass >= here.pre || s4.y + here.mass >= here.pre ||
-                                         s4.z + here.mass >= here.pre || s4.w + here.mass >= here.pre;
-                        if (__ballot(any) == 0) continue;
-                        // sums of the four rows in one coalesced load (the array is padded by four entries)
-                        const float4 sums4 = *reinterpret_cast<const float4 *>(&a.sums32[tile_base + idx]);
-                        const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
-                        const uint32_t rows4[4] = {static_cast<uint32_t>(idx), static_cast<uint32_t>(idx + 1),
-                                                   static_cast<uint32_t>(idx + 2), static_cast<uint32_t>(idx + 3)};
-                        const float bound4[4] = {sums4.x, sums4.y, sums4.z, sums4.w};
-                        const float mass4[4] = {here.mass, here.mass, here.mass, here.mass};
-                        consider4(sv, rows4, bound4, mass4);
+                    const int r1 = limit;
+                    // a flood is only to be expected while there is no threshold, while it is young, or when the last
+                    // step appended a lot; otherwise zero on the fly (one LDS pass and one barrier less) and treat an
+                    // overflow as fatal.  Without a threshold every positive row is appended: a tile with more than
+                    // a buffer's worth of them overflows once, which yields a threshold from ~1800 samples.
+                    const bool recoverable = !tight || selects <= 2 || last_appended > 128;
+                    // four scan iterations per batch: their `sums32` loads are issued together, ahead of the LDS
+                    // work, so a batch exposes one HBM latency instead of four
+                    constexpr int kBatch = 4;
+                    for (int base = ((a.debug & 8) && b > 0) ? r1 : r0 + tid * 4; base < r1; base += kBatch * kThreads * 4) {
+                        float4 sums4[kBatch];
+#pragma unroll
+                        for (int it = 0; it < kBatch; ++it) {
+                            const int idx = base + it * kThreads * 4;
+                            sums4[it] = (idx < r1 && DS_OK_INDEX(5, tile_base + idx + 3, a.n_truth + 4))
+                                            ? *reinterpret_cast<const float4 *>(&a.sums32[tile_base + idx])
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+#pragma unroll
+                        for (int it = 0; it < kBatch; ++it) {
+                            const int idx = base + it * kThreads * 4;
+                            if (idx >= r1) continue;
+                            const uint4 raw4 = *reinterpret_cast<uint4 *>(&iscores[idx]);
+                            if (!recoverable) *reinterpret_cast<uint4 *>(&iscores[idx]) = make_uint4(0u, 0u, 0u, 0u);
+                            const float4 s4 = make_float4(static_cast<float>(raw4.x) * from_fixed,
+                                                          static_cast<float>(raw4.y) * from_fixed,
+                                                          static_cast<float>(raw4.z) * from_fixed,
+                                                          static_cast<float>(raw4.w) * from_fixed);
+                            // mass < pre by construction, so untouched rows (score 0) never pass
+                            const bool any = s4.x + here.mass >= here.pre || s4.y + here.mass >= here.pre ||
+                                             s4.z + here.mass >= here.pre || s4.w + here.mass >= here.pre;
+                            if (__ballot(any) == 0) continue;
+                            if ((a.debug & 4) && b > 0) continue;
+                            const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+                            const uint32_t rows4[4] = {static_cast<uint32_t>(idx), static_cast<uint32_t>(idx + 1),
+                                                       static_cast<uint32_t>(idx + 2), static_cast<uint32_t>(idx + 3)};
+                            const float bound4[4] = {sums4[it].x, sums4[it].y, sums4[it].z, sums4[it].w};
+                            const float mass4[4] = {here.mass, here.mass, here.mass, here.mass};
+                            consider4(sv, rows4, bound4, mass4);
+                        }
                     }
                     __syncthreads();
                     last_appended = ctrl[kLCount] - count_at_step;
@@ -713,7 +763,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     continue;
                 }
                 // ---- tighten: tau = k-th largest lower estimate seen so far; keep what can still qualify
-                const uint32_t tau_key = radix_select_kth(cand_key, m, k, hist, ctrl);
+                const uint32_t tau_key = radix_select_kth(cand_key, m, k, hist, ctrl, 2);
                 ++selects;
                 if (wave == 0) {
                     const double tau = static_cast<double>(__uint_as_float(tau_key));
@@ -809,9 +859,11 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                 drop_lo = drop_hi = 0;
                 __syncthreads();
                 const int kept = ctrl[kLCount];
+                __syncthreads();  // a retried scan appends right away: the count must be read by all threads first
                 if (kept > kSelectTrigger) { slow = true; reason = 4; break; }  // massive ties: use the dense kernel
                 next_select = min(kSelectTrigger, max(2 * kept, max(4 * k, 64)));
                 first_raw = kept;
+                count_at_step = kept;
                 DS_STAMP(4);
             }
         }
@@ -825,7 +877,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
         if (!slow) {
             // final tightening so that only k + near-ties + margin survivors are evaluated exactly
             if (m > k) {
-                const uint32_t tau_key = radix_select_kth(cand_key, m, k, hist, ctrl);
+                const uint32_t tau_key = radix_select_kth(cand_key, m, k, hist, ctrl, 4);
                 ++selects;
                 const double tau = static_cast<double>(__uint_as_float(tau_key));
                 const double cut_value = tau - 2.0 * margin - 2e-6;
@@ -861,6 +913,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             for (int p = tid; p < m * n; p += kThreads) {  // one (candidate, column) membership test per thread
                 const int i = p / n, j = p - i * n;
                 const int32_t t = cand_row[i];
+                if (!DS_OK_INDEX(6, t, a.n_truth)) continue;
                 bool hit;
                 if (sig_bit[j] >= 0) {
                     const uint32_t *words = reinterpret_cast<const uint32_t *>(a.signature + t);
@@ -874,9 +927,10 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     uint32_t hi = end;
                     while (lo < hi) {
                         const uint32_t mid = (lo + hi) >> 1;
+                        if (!DS_OK_INDEX(9, mid, a.n_quads * 4)) break;
                         if (a.postings[mid] < local) lo = mid + 1; else hi = mid;
                     }
-                    hit = lo < end && a.postings[lo] == local;
+                    hit = lo < end && DS_OK_INDEX(10, lo, a.n_quads * 4) && a.postings[lo] == local;
                 }
                 if (hit) atomicOr(&hit_mask[i * 4 + (j >> 5)], 1u << (j & 31));
             }
@@ -892,6 +946,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     }
                 }
                 const double s = static_cast<double>(score);
+                if (!DS_OK_INDEX(7, cand_row[i], a.n_truth)) continue;
                 exact_jaccard[i] = s / (static_cast<double>(a.sums32[cand_row[i]]) + (maxint - s));  // :50
             }
             __syncthreads();
@@ -922,7 +977,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     const int32_t t = cand_row[i];
                     int above = 0;
                     for (int j = 0; j < m; ++j) above += (exact_jaccard[j] >= threshold) && cand_row[j] > t;
-                    if (above < k) a.out_rows[q * k + above] = t;
+                    if (above < k && DS_OK_INDEX(8, q * k + above, a.n_queries * k)) a.out_rows[q * k + above] = t;
                 }
             }
             __syncthreads();
@@ -950,6 +1005,8 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             DS_STAMP(0);
         }
     }
+    if (a.phase != nullptr && tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&a.phase[i], phase_lds[i]);
 }
 
 // ---- the literal algorithm for the queries the fast kernel hands over ------------------------------------------------
@@ -1144,9 +1201,10 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     if (const char *limit = getenv("DS_SPARSE_QUADS"); limit != nullptr) args.sparse_quads = atoi(limit);
     args.sums_min = index->sums_min;
     args.debug = 0;
+    args.n_quads = index->n_quads;
     args.refine_batch = kRefineBatch;
-    if (const char *batch = getenv("DS_REFINE_BATCH"); batch != nullptr) args.refine_batch = atoi(batch);
     if (const char *debug = getenv("DS_DEBUG"); debug != nullptr) args.debug = atoi(debug);
+    if (const char *batch = getenv("DS_REFINE_BATCH"); batch != nullptr) args.refine_batch = atoi(batch);
 
     const int grid = static_cast<int>(std::min<int64_t>(Q, index->compute_units));
     DS_HIP(hipMemsetAsync(index->control.ptr, 0, kControlWords * sizeof(int32_t), stream));
@@ -1195,7 +1253,7 @@ static int collect(ds_index *index, hipStream_t stream, int64_t stats[32])
         } else {
             stats[26] = stats[27] = 0;
         }
-        for (int i = 28; i < 32; ++i) stats[i] = 0;
+        for (int i = 28; i < 32; ++i) stats[i] = control[24 + (i - 28)];  // bounds-check record of debug builds
     }
     if (control[kCtlErrors] != 0 && index->last_queries > 0) {
         std::vector<int32_t> status(static_cast<size_t>(index->last_queries));

@@ -101,7 +101,7 @@ class TruthIndex:
                                           list(stats)[16:22])),
                 "refines": stats[22], "raw_entries": stats[23], "refine_survivors": stats[24],
                 "raw_entries_sparse": stats[25], "topk_kernel_ms": stats[26] / 1000.0,
-                "dense_kernel_ms": stats[27] / 1000.0}
+                "dense_kernel_ms": stats[27] / 1000.0, "bounds_record": list(stats)[28:32]}
 
     def close(self):
         if self.handle:
