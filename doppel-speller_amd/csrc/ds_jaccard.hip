@@ -95,6 +95,7 @@ constexpr int kRefineRoom = 640;   // refine when fewer free candidate slots tha
 constexpr int kKeep = (kCandidates + kThreads - 1) / kThreads;  // candidate entries a thread holds while compacting
 constexpr int kSelectTrigger = kCandidates - kLooseStep;
 constexpr int kWaves = kThreads / 64;
+constexpr int kProbeMaxK = kThreads / 4;  // threshold bootstrap from per-thread samples: k well below the sample count
 constexpr int kUnits = kThreads >= 1024 ? 1 : 2;  // chunks of 4 quads per lane in flight per wave (register budget)
 
 // LDS control words
@@ -678,10 +679,43 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             if (!sparse) ++dense_tiles;
             bool select_now = sparse && first_raw == ctrl[kLCount] && ctrl[kLCount] >= next_select;
             int retries = 0;
+            bool probed = false;
             int32_t drop_lo = 0, drop_hi = 0;  // rows to drop at the next pruning (a step that is scanned again)
             while (r0 < limit || select_now) {
                 bool force_select = false;
-                if (r0 < limit) {
+                if (r0 < limit && !tight && !probed && k <= kProbeMaxK && count_at_step == 0) {
+                    // ---- threshold bootstrap.  No threshold yet and nothing buffered: instead of flooding the
+                    // candidate buffer with every positive row, each thread picks the best of its 32 rows of this
+                    // tile (cross-multiplied comparison, no division) and contributes that row's key as a SAMPLE
+                    // (row = -1: dropped by the compaction below).  The k-th largest of the kThreads samples is the
+                    // k-th largest value of a subset of the rows, i.e. a valid lower estimate of the final k-th.
+                    probed = true;
+                    float best_s = 0.f, best_d = 1.f, best_sums = 0.f;
+                    for (int idx = tid * 4; idx < limit; idx += kThreads * 4) {
+                        const float4 sums4 = *reinterpret_cast<const float4 *>(&a.sums32[tile_base + idx]);
+                        const uint4 raw4 = *reinterpret_cast<uint4 *>(&iscores[idx]);
+                        const float sv[4] = {static_cast<float>(raw4.x) * from_fixed, static_cast<float>(raw4.y) * from_fixed,
+                                             static_cast<float>(raw4.z) * from_fixed, static_cast<float>(raw4.w) * from_fixed};
+                        const float su[4] = {sums4.x, sums4.y, sums4.z, sums4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = su[e] + maxint32;
+                            if (sv[e] * best_d > best_s * d) {
+                                best_s = sv[e];
+                                best_d = d;
+                                best_sums = su[e];
+                            }
+                        }
+                    }
+                    uint32_t sample = 0u;
+                    if (best_s > 0.f && !candidate_key(best_s, best_sums, bounds, sample)) sample = 0u;
+                    cand_key[tid] = sample;
+                    cand_row[tid] = -1;
+                    if (tid == 0) ctrl[kLCount] = kThreads;
+                    __syncthreads();
+                    first_raw = kThreads;
+                    force_select = true;
+                } else if (r0 < limit) {
                     // no running value yet: 512-row steps; afterwards the whole rest of the tile.  The scores of a step
                     // are zeroed only once the step has fitted into the candidate buffer: if a flood of rows above a
                     // still weak threshold overflows it, the step is undone, the threshold is tightened from what is
