@@ -15,14 +15,27 @@
 namespace ds {
 
 // ---- geometry of the Jaccard kernels (see DESIGN.md "HBM layout") ------------------------------------------------
-constexpr int kTileLog2 = 15;
-constexpr int kTile = 1 << kTileLog2;        // truth rows per tile: one float32 score per row fills 128 KiB of LDS
-constexpr int kSentinel = kTile;             // padding entry of a posting quad: lands in the trash slot scores[kTile]
-constexpr int kThreads = 1024;               // one 8-wave workgroup per CU (<= 256 VGPRs per lane)
+// Fast kernel: two 512-thread workgroups per CU (independent queries hide each other's latencies and barriers); a
+// workgroup's score tile holds one 16-bit fixed-point score per row, two rows per LDS word.
+#ifndef DS_TILE_ROWS
+#define DS_TILE_ROWS 28672
+#endif
+#ifndef DS_CANDIDATES
+#define DS_CANDIDATES 1536
+#endif
+#ifndef DS_PTR_TILES
+#define DS_PTR_TILES 4
+#endif
+constexpr int kTile = DS_TILE_ROWS;          // truth rows per tile (multiple of 4096): 56 KiB of packed 16-bit scores
+constexpr int kSentinel = kTile;             // padding entry of a posting quad: lands in the trash word after the tile
+constexpr int kThreads = 512;                // fast kernel: 8 waves per workgroup, 2 workgroups per CU
+constexpr int kWorkgroupsPerCu = 2;
+constexpr int kDenseThreads = 1024;          // literal kernel: one 16-wave workgroup per CU, float32 score tile
+static_assert(kTile % 4096 == 0 && kTile < 65536, "tile rows: whole scan iterations, 16-bit local indexes");
 constexpr int kMaxQueryColumns = 128;        // fast-path limit (example data: p99 50, max 96 tri-grams per title)
-constexpr int kCandidates = 1792;            // capacity of the per-query candidate buffer in LDS
+constexpr int kCandidates = DS_CANDIDATES;            // capacity of the per-query candidate buffer in LDS
 constexpr int kLooseStep = 512;              // rows scanned between two capacity checks while no threshold exists
-constexpr int kPtrTiles = 8;                 // tiles whose list pointers are cached in LDS at a time
+constexpr int kPtrTiles = DS_PTR_TILES;                 // tiles whose list pointers are cached in LDS at a time
 constexpr int kItemQuads = 256;              // a work item = up to 256 posting quads of one (tile, column) list
 constexpr int kMaxItems = 512;               // work items per (query, tile); more => dense kernel
 constexpr int kSignatureBits = 128;          // densest columns whose membership is kept as a per-row bit (uint4)

@@ -68,8 +68,8 @@ enum { kCtlQueue = 0, kCtlSlowCount = 1, kCtlErrors = 2, kCtlExact = 3, kCtlSele
        kCtlRefines = 16, kCtlRawEntries = 17, kCtlSurvivors = 18, kCtlRawSparse = 19 };
 
 // LDS carve-up of the fast kernel (bytes)
-constexpr int kScoreFloats = kTile + 64;  // + trash slot for the padding entries of a quad
-constexpr int kOffLo = kScoreFloats * 4;
+constexpr int kScoreWords = kTile / 2 + 16;  // two 16-bit scores per word + the trash word of the padding entries
+constexpr int kOffLo = kScoreWords * 4;
 constexpr int kOffRow = kOffLo + kCandidates * 4;
 constexpr int kOffCols = kOffRow + kCandidates * 4;
 constexpr int kOffIdf = kOffCols + kMaxQueryColumns * 4;
@@ -85,22 +85,29 @@ constexpr int kOffBegin = kOffMassTable + 256 * 4;
 constexpr int kOffEnd = kOffBegin + kMaxQueryColumns * 4;
 constexpr int kOffPtr = kOffEnd + kMaxQueryColumns * 4;
 constexpr int kOffItems = kOffPtr + kMaxQueryColumns * (kPtrTiles + 1) * 4;
-constexpr int kOffHist = kOffItems + kMaxItems * 2;
+constexpr int kOffHist = kOffItems + kMaxQueryColumns * 4;
 constexpr int kOffCtrl = kOffHist + 256 * 4;
 constexpr int kFastLdsBytes = kOffCtrl + 128;
-static_assert(kFastLdsBytes <= 160 * 1024, "LDS budget of one CU exceeded");
-static_assert(kMaxQueryColumns == 128 && kItemQuads == 256, "item encoding: 7 bits column, 5 bits chunk");
+static_assert((kFastLdsBytes + 256) * kWorkgroupsPerCu <= 160 * 1024, "LDS budget of one CU exceeded");
+static_assert(kCandidates * 16 <= 32768 && 32768 + kCandidates * 8 <= kTile * 2, "exact-stage scratch fits the tile");
+static_assert(kMaxQueryColumns == 128, "two ballots cover the query's columns");
 constexpr int kRefineBatch = 128;  // raw entries that make a refine pass worth its three barriers
-constexpr int kRefineRoom = 640;   // refine when fewer free candidate slots than this remain
+constexpr int kRefineRoom = 512;   // refine when fewer free candidate slots than this remain
 constexpr int kKeep = (kCandidates + kThreads - 1) / kThreads;  // candidate entries a thread holds while compacting
 constexpr int kSelectTrigger = kCandidates - kLooseStep;
 constexpr int kWaves = kThreads / 64;
+#ifndef DS_SCAN_BATCH
+#define DS_SCAN_BATCH 2
+#endif
+constexpr float kFixedOne = 65000.f;  // fixed-point value of the query's total IDF mass (+ n <= 128 roundings < 2^16)
 constexpr int kProbeMaxK = kThreads / 4;  // threshold bootstrap from per-thread samples: k well below the sample count
-constexpr int kUnits = kThreads >= 1024 ? 1 : 2;  // chunks of 4 quads per lane in flight per wave (register budget)
+constexpr int kUnits = 2;  // chunks of 4 quads per lane in flight per wave (register budget)
 
 // LDS control words
 enum { kLQuery = 0, kLCount, kLOverflow, kLDigit, kLRemain, kLCoef, kLPre, kLCut, kLKth0, kLKth1, kLBad, kLItems,
-       kLQuads, kLNonEssential, kLMass, kLSparse, kLSigMask /* 4 words */, kLEnd = kLSigMask + 4 };
+       kLQuads, kLNonEssential, kLMass, kLSparse, kLSigMask /* 4 words */, kLEnd = kLSigMask + 4,
+       kLTileMin = 24 /* kPtrTiles floats: min sums32 of the cached tiles */ };
+static_assert(kLEnd <= kLTileMin && kLTileMin + kPtrTiles <= 32, "LDS control words");
 
 __device__ __forceinline__ float round_down_positive(double x)
 {
@@ -220,6 +227,20 @@ __device__ __forceinline__ float complete_score(float s, uint4 signature, const 
     return s;
 }
 
+// Packed score tile: row r lives in half (r & 1) of word r >> 1.
+__device__ __forceinline__ void add_packed(uint32_t *iscores, uint32_t local, uint32_t value)
+{
+    atomicAdd(&iscores[local >> 1], value << ((local & 1u) << 4));
+}
+
+// Takes a row's score and leaves zero behind (the other half of the word is untouched).
+__device__ __forceinline__ uint32_t take_packed(uint32_t *iscores, uint32_t local)
+{
+    const uint32_t shift = (local & 1u) << 4;
+    const uint32_t old = atomicAnd(&iscores[local >> 1], ~(0xffffu << shift));
+    return (old >> shift) & 0xffffu;
+}
+
 // Wave-aggregated append to the candidate buffer.  Must be called by all active lanes of the wave together.
 __device__ __forceinline__ void append_candidate(bool pass, uint32_t key, int32_t row, uint32_t *cand_key,
                                                  int32_t *cand_row, volatile int32_t *ctrl, int lane)
@@ -270,13 +291,12 @@ __device__ __forceinline__ bool in_bounds(int32_t *control, int site, int64_t in
         }                                                                  \
     } while (0)
 
-__global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a)
+__global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void ds_jaccard_topk_kernel(JaccardArgs a)
 {
     unsigned long long stamp_ = a.phase != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
-    __shared__ unsigned long long phase_lds[8];
-    if (threadIdx.x < 8) phase_lds[threadIdx.x] = 0ull;
+    __shared__ unsigned long long phase_lds[16];
+    if (threadIdx.x < 16) phase_lds[threadIdx.x] = 0ull;
     extern __shared__ __align__(16) unsigned char lds[];
-    float *scores = reinterpret_cast<float *>(lds);
     uint32_t *cand_key = reinterpret_cast<uint32_t *>(lds + kOffLo);
     int32_t *cand_row = reinterpret_cast<int32_t *>(lds + kOffRow);
     int32_t *cols = reinterpret_cast<int32_t *>(lds + kOffCols);
@@ -287,14 +307,14 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
     int32_t *sig_bit = reinterpret_cast<int32_t *>(lds + kOffSigBit);  // signature bit of column j or -1
     float *bit_idf = reinterpret_cast<float *>(lds + kOffBitIdf);     // IDF of the query column owning signature bit g
     uint32_t *fixed = reinterpret_cast<uint32_t *>(lds + kOffFixed);  // idf[j] in the query's fixed-point scale
-    uint32_t *iscores = reinterpret_cast<uint32_t *>(lds);           // the score tile holds fixed-point sums
+    uint32_t *iscores = reinterpret_cast<uint32_t *>(lds);  // score tile: 16-bit fixed-point sums, row r in half (r & 1) of word r >> 1
     uint32_t *col_total = reinterpret_cast<uint32_t *>(lds + kOffTotal);  // quads of column j over all tiles
     // mass_table[b] = upper bound of what the skipped columns add to a row whose signature bits 0..7 are b
     float *mass_table = reinterpret_cast<float *>(lds + kOffMassTable);
     uint32_t *list_begin = reinterpret_cast<uint32_t *>(lds + kOffBegin);
     uint32_t *list_end = reinterpret_cast<uint32_t *>(lds + kOffEnd);
     uint32_t *ptr_cache = reinterpret_cast<uint32_t *>(lds + kOffPtr);  // [column][kPtrTiles + 1]
-    uint16_t *items = reinterpret_cast<uint16_t *>(lds + kOffItems);
+    uint32_t *item_first = reinterpret_cast<uint32_t *>(lds + kOffItems);  // [column] work items before column j
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + kOffHist);
     volatile int32_t *ctrl = reinterpret_cast<volatile int32_t *>(lds + kOffCtrl);
 
@@ -304,8 +324,8 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
     const uint2 *quads = reinterpret_cast<const uint2 *>(a.postings);
     const uint2 *sums_quads = reinterpret_cast<const uint2 *>(a.posting_sums);
 
-    for (int i = tid * 4; i < kScoreFloats; i += kThreads * 4)
-        *reinterpret_cast<float4 *>(&scores[i]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid * 4; i < kScoreWords; i += kThreads * 4)
+        *reinterpret_cast<uint4 *>(&iscores[i]) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
 
     for (;;) {
@@ -367,14 +387,16 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
 
         const float maxint32 = static_cast<float>(maxint);
         __syncthreads();
-        // Scores are accumulated in unsigned fixed point (LDS integer atomics run ~14x faster than ds_add_f32 on
-        // gfx950 and are order-independent): one unit = total/2^30 where total >= every reachable score.
+        // Scores are accumulated in unsigned 16-bit fixed point, two rows per LDS word (LDS integer atomics run ~14x
+        // faster than ds_add_f32 on gfx950 and are order-independent): one unit = total/kFixedOne where total >=
+        // every reachable score.  A row's sum is at most kFixedOne + n (every term rounds by < 1 unit) < 65536, so
+        // the low half of a word never carries into the high half.
         const float total_mass = n > 0 ? fmaxf(maxint32, mass_upto[n - 1]) : maxint32;
-        const float to_fixed = 1073741824.f / total_mass, from_fixed = total_mass * 9.313225746154785e-10f;
+        const float to_fixed = kFixedOne / total_mass, from_fixed = total_mass * (1.f / kFixedOne);
         if (tid < n) fixed[tid] = max(1u, static_cast<uint32_t>(idf[tid] * to_fixed + 0.5f));
         // |approximate jaccard - exact jaccard| <= margin (DESIGN.md "error margin of the prefilter"):
-        // float32 evaluation + quantisation of n terms to 2^-30 of the total
-        const double margin = (6.0 * n + 64.0) * 5.9604644775390625e-08 + n * 3.725290298461914e-09;
+        // float32 evaluation + quantisation of n terms to one unit each (4 = bound of d jaccard / d score * total)
+        const double margin = (6.0 * n + 64.0) * 5.9604644775390625e-08 + n * (4.0 / kFixedOne) * 1.001;
         Bounds bounds{0.f, FLT_MIN, 0.f, maxint32};
         float cut = 0.f, pending_mass = 0.f;  // mass of the columns skipped from the NEXT tile on
         uint32_t pending_sig_mask[kSignatureWords] = {0u, 0u, 0u, 0u};
@@ -397,6 +419,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
         auto refine = [&]() {
             const int last_raw = min(static_cast<int>(ctrl[kLCount]), kCandidates);
             if (last_raw <= first_raw) return;
+            DS_STAMP(10);
             if (tid == 0 && a.phase != nullptr) {
                 atomicAdd(&a.control[kCtlRefines], 1);
                 atomicAdd(&a.control[kCtlRawEntries], last_raw - first_raw);
@@ -439,6 +462,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             if (tid == 0 && a.phase != nullptr) atomicAdd(&a.control[kCtlSurvivors], ctrl[kLCount] - first_raw);
             first_raw = ctrl[kLCount];
             __syncthreads();  // every thread holds the same count before anything is appended again
+            DS_STAMP(8);
         };
         // refine when raw entries pile up, when a selection is due, or when the buffer runs short of room
         auto refine_due = [&]() {
@@ -446,20 +470,39 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             return count - first_raw >= refine_batch || count > kCandidates - kRefineRoom;
         };
 
+        // List pointers of kPtrTiles tiles for every query column (+ the tiles' min sums32), loaded into registers
+        // one tile before they are needed so that their latency hides behind that tile's work.
+        constexpr int kPrefetch = (kMaxQueryColumns * (kPtrTiles + 1) + kThreads - 1) / kThreads;
+        uint32_t pre_ptr[kPrefetch];
+        float pre_min = 0.f;
+        auto prefetch = [&](int b0) {
+            const int width = min(kPtrTiles, a.n_tiles - b0) + 1;
+#pragma unroll
+            for (int r = 0; r < kPrefetch; ++r) {
+                const int e = tid + r * kThreads;
+                const int j = e / (kPtrTiles + 1), i = e % (kPtrTiles + 1);
+                const bool ok = e < n * (kPtrTiles + 1) && i < width &&
+                                DS_OK_INDEX(2, static_cast<int64_t>(cols[j < n ? j : 0]) * ptr_stride + b0 + i,
+                                            a.n_columns * ptr_stride);
+                pre_ptr[r] = ok ? a.col_ptr[static_cast<int64_t>(cols[j]) * ptr_stride + b0 + i] : 0u;
+            }
+            pre_min = (tid < kPtrTiles && b0 + tid < a.n_tiles) ? a.tile_sums_min[b0 + tid] : 0.f;
+        };
+        if (!slow) prefetch(0);
+
         for (int b = 0; b < a.n_tiles && !slow; ++b) {
             const int bt = b % kPtrTiles;
-            if (bt == 0) {  // list pointers of the next kPtrTiles tiles for every query column: one coalesced burst
+            if (bt == 0) {  // list pointers + min sums of the next kPtrTiles tiles: fetched one tile ahead, published here
                 __syncthreads();
-                const int width = min(kPtrTiles, a.n_tiles - b) + 1;
-                for (int e = tid; e < n * (kPtrTiles + 1); e += kThreads) {
-                    const int j = e / (kPtrTiles + 1), i = e % (kPtrTiles + 1);
-                    ptr_cache[e] = (i < width && DS_OK_INDEX(2, static_cast<int64_t>(cols[j]) * ptr_stride + b + i,
-                                                            a.n_columns * ptr_stride))
-                                       ? a.col_ptr[static_cast<int64_t>(cols[j]) * ptr_stride + b + i]
-                                       : 0u;
+#pragma unroll
+                for (int r = 0; r < kPrefetch; ++r) {
+                    const int e = tid + r * kThreads;
+                    if (e < n * (kPtrTiles + 1)) ptr_cache[e] = pre_ptr[r];
                 }
+                if (tid < kPtrTiles) ctrl[kLTileMin + tid] = __float_as_int(pre_min);
                 __syncthreads();
             }
+            if (bt == kPtrTiles - 1 && b + 1 < a.n_tiles) prefetch(b + 1);
             // ---- work items of this tile: (column, chunk of kItemQuads quads) for every essential column
             // raw entries were scored under the current set of skipped columns: refine them before it changes
             if (non_essential != skipped.count && first_raw != ctrl[kLCount]) refine();
@@ -486,7 +529,9 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             int n_items = 0;
             if (!sparse) {
                 if (wave == 0) {
-                    uint32_t length[2], count[2];
+                    // item_first[j] = number of 256-quad work items of the columns before j (exclusive scan); a wave
+                    // finds the column of item `it` as the last j with item_first[j] <= it (two ballots)
+                    uint32_t count[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int j = lane + 64 * h;
@@ -497,37 +542,31 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                         }
                         list_begin[j] = begin;
                         list_end[j] = end;
-                        length[h] = end - begin;
-                        count[h] = (length[h] + kItemQuads - 1) / kItemQuads;
+                        count[h] = (end - begin + kItemQuads - 1) / kItemQuads;
                     }
                     const uint32_t scan0 = wave_inclusive_scan(count[0], lane);
                     const uint32_t total0 = __shfl(scan0, 63);
-                    const uint32_t scan1 = wave_inclusive_scan(count[1], lane);
-                    const uint32_t total1 = __shfl(scan1, 63);
-                    const uint32_t total_items = total0 + total1;
-                    if (total_items <= kMaxItems) {
-                        uint32_t at = scan0 - count[0];
-                        for (uint32_t c = 0; c < count[0]; ++c)
-                            items[at + c] = static_cast<uint16_t>(lane | (c << 7));
-                        at = total0 + scan1 - count[1];
-                        for (uint32_t c = 0; c < count[1]; ++c)
-                            items[at + c] = static_cast<uint16_t>((lane + 64) | (c << 7));
+                    uint32_t scan1 = 0, total1 = 0;
+                    if (n > 64) {
+                        scan1 = wave_inclusive_scan(count[1], lane);
+                        total1 = __shfl(scan1, 63);
                     }
-                    if (lane == 0) ctrl[kLItems] = static_cast<int32_t>(total_items);
+                    item_first[lane] = scan0 - count[0];
+                    item_first[lane + 64] = total0 + scan1 - count[1];
+                    if (lane == 0) ctrl[kLItems] = static_cast<int32_t>(total0 + total1);
                 }
                 __syncthreads();
                 n_items = ctrl[kLItems];
-                if (n_items > kMaxItems) { slow = true; reason = 1; break; }
             }
             DS_STAMP(1);
 
-            const int64_t tile_base = static_cast<int64_t>(b) << kTileLog2;
+            const int64_t tile_base = static_cast<int64_t>(b) * kTile;
             // read here, where a barrier (end of the scatter) separates every thread's read from the next append
             int count_at_step = ctrl[kLCount];
             // row-independent gate of this tile: coef * (min sums of the tile + maxint), rounded down
             Bounds here = bounds;
             {
-                const float gate = bounds.coef * (a.tile_sums_min[b] + maxint32) * (1.f - 3.814697265625e-06f);
+                const float gate = bounds.coef * (__int_as_float(ctrl[kLTileMin + bt]) + maxint32) * (1.f - 3.814697265625e-06f);
                 if (gate > here.pre) here.pre = gate;
             }
             // A sweep only runs the register-level tests and appends RAW entries (approximate essential score, row);
@@ -589,7 +628,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                             const uint32_t index = first[u >> 2] + (u & 3) * 64 + lane;
                             live[u] = index < last[u >> 2];
                             live[u] = live[u] && DS_OK_INDEX(3, index, a.n_quads);
-                            quad[u] = live[u] ? quads[index] : make_uint2(0x80008000u, 0x80008000u);
+                            quad[u] = live[u] ? quads[index] : make_uint2(kSentinel * 0x10001u, kSentinel * 0x10001u);
                             if (sweep == 1 && live[u]) quad_sums[u] = sums_quads[index];
                         }
                         if (sweep == 0) {
@@ -597,10 +636,10 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                             for (int u = 0; u < 4 * kUnits; ++u) {
                                 if (!live[u]) continue;
                                 const uint32_t v = value[u >> 2];
-                                atomicAdd(&iscores[quad[u].x & 0xffffu], v);
-                                atomicAdd(&iscores[quad[u].x >> 16], v);
-                                atomicAdd(&iscores[quad[u].y & 0xffffu], v);
-                                atomicAdd(&iscores[quad[u].y >> 16], v);
+                                add_packed(iscores, quad[u].x & 0xffffu, v);
+                                add_packed(iscores, quad[u].x >> 16, v);
+                                add_packed(iscores, quad[u].y & 0xffffu, v);
+                                add_packed(iscores, quad[u].y >> 16, v);
                             }
                         } else {
 #pragma unroll
@@ -613,7 +652,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                                 uint32_t taken[4];
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
-                                    taken[e] = (live[u] && local[e] < kTile) ? atomicExch(&iscores[local[e]], 0u) : 0u;
+                                    taken[e] = (live[u] && local[e] < kTile) ? take_packed(iscores, local[e]) : 0u;
                                 if (!(a.debug & 2)) {
                                     const float s4[4] = {static_cast<float>(taken[0]) * from_fixed,
                                                          static_cast<float>(taken[1]) * from_fixed,
@@ -645,9 +684,11 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     for (int h = 0; h < kUnits; ++h) {
                         const int at = it + h * kWaves;
                         const bool item_ok = at < n_items;
-                        const uint32_t item = item_ok ? items[at] : 0u;
-                        const int j = item & 127u;
-                        const uint32_t first = list_begin[j] + (item >> 7) * kItemQuads + lane;
+                        const uint32_t want = static_cast<uint32_t>(at);
+                        const int before = __popcll(__ballot(item_first[lane] <= want)) +
+                                           __popcll(__ballot(item_first[lane + 64] <= want));
+                        const int j = item_ok ? before - 1 : 0;
+                        const uint32_t first = list_begin[j] + (want - item_first[j]) * kItemQuads + lane;
                         const uint32_t end = item_ok ? list_end[j] : 0u;
                         value[h] = fixed[j];
 #pragma unroll
@@ -662,10 +703,10 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     for (int u = 0; u < 4 * kUnits; ++u) {
                         if (!live[u]) continue;
                         const uint32_t v = value[u >> 2];
-                        atomicAdd(&iscores[quad[u].x & 0xffffu], v);
-                        atomicAdd(&iscores[quad[u].x >> 16], v);
-                        atomicAdd(&iscores[quad[u].y & 0xffffu], v);
-                        atomicAdd(&iscores[quad[u].y >> 16], v);
+                        add_packed(iscores, quad[u].x & 0xffffu, v);
+                        add_packed(iscores, quad[u].x >> 16, v);
+                        add_packed(iscores, quad[u].y & 0xffffu, v);
+                        add_packed(iscores, quad[u].y >> 16, v);
                     }
                 }
                 __syncthreads();
@@ -674,7 +715,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
 
             // ---- (2d) dense scan (and re-zero) of the tile; in steps while no running value exists
             const int64_t rows_left = a.n_truth - tile_base;
-            const int limit = rows_left >= kTile ? kTile : static_cast<int>((rows_left + 3) & ~int64_t(3));
+            const int limit = rows_left >= kTile ? kTile : static_cast<int>((rows_left + 7) & ~int64_t(7));
             int r0 = sparse ? limit : 0;
             if (!sparse) ++dense_tiles;
             bool select_now = sparse && first_raw == ctrl[kLCount] && ctrl[kLCount] >= next_select;
@@ -691,17 +732,19 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     // k-th largest value of a subset of the rows, i.e. a valid lower estimate of the final k-th.
                     probed = true;
                     float best_s = 0.f, best_d = 1.f, best_sums = 0.f;
-                    for (int idx = tid * 4; idx < limit; idx += kThreads * 4) {
-                        const float4 sums4 = *reinterpret_cast<const float4 *>(&a.sums32[tile_base + idx]);
-                        const uint4 raw4 = *reinterpret_cast<uint4 *>(&iscores[idx]);
-                        const float sv[4] = {static_cast<float>(raw4.x) * from_fixed, static_cast<float>(raw4.y) * from_fixed,
-                                             static_cast<float>(raw4.z) * from_fixed, static_cast<float>(raw4.w) * from_fixed};
-                        const float su[4] = {sums4.x, sums4.y, sums4.z, sums4.w};
+                    for (int idx = tid * 8; idx < limit; idx += kThreads * 8) {
+                        const float4 sums_lo = *reinterpret_cast<const float4 *>(&a.sums32[tile_base + idx]);
+                        const float4 sums_hi = *reinterpret_cast<const float4 *>(&a.sums32[tile_base + idx + 4]);
+                        const uint4 raw4 = *reinterpret_cast<uint4 *>(&iscores[idx >> 1]);
+                        const uint32_t words[4] = {raw4.x, raw4.y, raw4.z, raw4.w};
+                        const float su[8] = {sums_lo.x, sums_lo.y, sums_lo.z, sums_lo.w,
+                                             sums_hi.x, sums_hi.y, sums_hi.z, sums_hi.w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
+                        for (int e = 0; e < 8; ++e) {
+                            const float sv = static_cast<float>((words[e >> 1] >> ((e & 1) * 16)) & 0xffffu) * from_fixed;
                             const float d = su[e] + maxint32;
-                            if (sv[e] * best_d > best_s * d) {
-                                best_s = sv[e];
+                            if (sv * best_d > best_s * d) {
+                                best_s = sv;
                                 best_d = d;
                                 best_sums = su[e];
                             }
@@ -715,6 +758,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     __syncthreads();
                     first_raw = kThreads;
                     force_select = true;
+                    DS_STAMP(11);
                 } else if (r0 < limit) {
                     // no running value yet: 512-row steps; afterwards the whole rest of the tile.  The scores of a step
                     // are zeroed only once the step has fitted into the candidate buffer: if a flood of rows above a
@@ -726,42 +770,56 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     // overflow as fatal.  Without a threshold every positive row is appended: a tile with more than
                     // a buffer's worth of them overflows once, which yields a threshold from ~1800 samples.
                     const bool recoverable = !tight || selects <= 2 || last_appended > 128;
-                    // four scan iterations per batch: their `sums32` loads are issued together, ahead of the LDS
-                    // work, so a batch exposes one HBM latency instead of four
-                    constexpr int kBatch = 4;
-                    for (int base = ((a.debug & 8) && b > 0) ? r1 : r0 + tid * 4; base < r1; base += kBatch * kThreads * 4) {
-                        float4 sums4[kBatch];
+                    // A thread reads eight rows (one uint4 of packed scores) per iteration; the `sums32` loads of a
+                    // batch of iterations are issued together, ahead of the LDS work, so a batch exposes one HBM latency.
+                    constexpr int kBatch = DS_SCAN_BATCH;
+                    for (int base = ((a.debug & 8) && b > 0) ? r1 : r0 + tid * 8; base < r1; base += kBatch * kThreads * 8) {
+                        float4 sums_lo[kBatch], sums_hi[kBatch];
 #pragma unroll
                         for (int it = 0; it < kBatch; ++it) {
-                            const int idx = base + it * kThreads * 4;
-                            sums4[it] = (idx < r1 && DS_OK_INDEX(5, tile_base + idx + 3, a.n_truth + 4))
-                                            ? *reinterpret_cast<const float4 *>(&a.sums32[tile_base + idx])
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                            const int idx = base + it * kThreads * 8;
+                            const bool ok = idx < r1 && DS_OK_INDEX(5, tile_base + idx + 7, a.n_truth + 8);
+                            sums_lo[it] = ok ? *reinterpret_cast<const float4 *>(&a.sums32[tile_base + idx])
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                            sums_hi[it] = ok ? *reinterpret_cast<const float4 *>(&a.sums32[tile_base + idx + 4])
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
                         }
 #pragma unroll
                         for (int it = 0; it < kBatch; ++it) {
-                            const int idx = base + it * kThreads * 4;
+                            const int idx = base + it * kThreads * 8;
                             if (idx >= r1) continue;
-                            const uint4 raw4 = *reinterpret_cast<uint4 *>(&iscores[idx]);
-                            if (!recoverable) *reinterpret_cast<uint4 *>(&iscores[idx]) = make_uint4(0u, 0u, 0u, 0u);
-                            const float4 s4 = make_float4(static_cast<float>(raw4.x) * from_fixed,
-                                                          static_cast<float>(raw4.y) * from_fixed,
-                                                          static_cast<float>(raw4.z) * from_fixed,
-                                                          static_cast<float>(raw4.w) * from_fixed);
-                            // mass < pre by construction, so untouched rows (score 0) never pass
-                            const bool any = s4.x + here.mass >= here.pre || s4.y + here.mass >= here.pre ||
-                                             s4.z + here.mass >= here.pre || s4.w + here.mass >= here.pre;
+                            const uint4 raw4 = *reinterpret_cast<uint4 *>(&iscores[idx >> 1]);
+                            if (!recoverable) *reinterpret_cast<uint4 *>(&iscores[idx >> 1]) = make_uint4(0u, 0u, 0u, 0u);
+                            const uint32_t words[4] = {raw4.x, raw4.y, raw4.z, raw4.w};
+                            float sv[8];
+                            bool any = false;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                sv[e] = static_cast<float>((words[e >> 1] >> ((e & 1) * 16)) & 0xffffu) * from_fixed;
+                                // mass < pre by construction, so untouched rows (score 0) never pass
+                                any = any || sv[e] + here.mass >= here.pre;
+                            }
                             if (__ballot(any) == 0) continue;
                             if ((a.debug & 4) && b > 0) continue;
-                            const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
-                            const uint32_t rows4[4] = {static_cast<uint32_t>(idx), static_cast<uint32_t>(idx + 1),
-                                                       static_cast<uint32_t>(idx + 2), static_cast<uint32_t>(idx + 3)};
-                            const float bound4[4] = {sums4[it].x, sums4[it].y, sums4[it].z, sums4[it].w};
                             const float mass4[4] = {here.mass, here.mass, here.mass, here.mass};
-                            consider4(sv, rows4, bound4, mass4);
+                            {
+                                const float s4[4] = {sv[0], sv[1], sv[2], sv[3]};
+                                const uint32_t rows4[4] = {static_cast<uint32_t>(idx), static_cast<uint32_t>(idx + 1),
+                                                           static_cast<uint32_t>(idx + 2), static_cast<uint32_t>(idx + 3)};
+                                const float bound4[4] = {sums_lo[it].x, sums_lo[it].y, sums_lo[it].z, sums_lo[it].w};
+                                consider4(s4, rows4, bound4, mass4);
+                            }
+                            {
+                                const float s4[4] = {sv[4], sv[5], sv[6], sv[7]};
+                                const uint32_t rows4[4] = {static_cast<uint32_t>(idx + 4), static_cast<uint32_t>(idx + 5),
+                                                           static_cast<uint32_t>(idx + 6), static_cast<uint32_t>(idx + 7)};
+                                const float bound4[4] = {sums_hi[it].x, sums_hi[it].y, sums_hi[it].z, sums_hi[it].w};
+                                consider4(s4, rows4, bound4, mass4);
+                            }
                         }
                     }
                     __syncthreads();
+                    DS_STAMP(3);
                     last_appended = ctrl[kLCount] - count_at_step;
                     if (ctrl[kLOverflow]) {
                         // the buffer holds as many of the step's rows as fitted: refine them, tighten the threshold
@@ -779,15 +837,16 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                         drop_hi = static_cast<int32_t>(tile_base + r1);
                     } else {
                         if (recoverable) {
-                            for (int idx = r0 + tid * 4; idx < r1; idx += kThreads * 4)
-                                *reinterpret_cast<uint4 *>(&iscores[idx]) = make_uint4(0u, 0u, 0u, 0u);
+                            for (int idx = r0 + tid * 8; idx < r1; idx += kThreads * 8)
+                                *reinterpret_cast<uint4 *>(&iscores[idx >> 1]) = make_uint4(0u, 0u, 0u, 0u);
                             __syncthreads();
+                            DS_STAMP(9);
                         }
                         r0 = r1;
                         retries = 0;
                         if (!tight || refine_due()) refine();
                     }
-                    DS_STAMP(3);
+                    DS_STAMP(12);
                 }
                 select_now = false;
                 const int m = ctrl[kLCount];
@@ -859,7 +918,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                 bounds.pre = __int_as_float(ctrl[kLPre]);
                 here.coef = bounds.coef;
                 {
-                    const float gate = bounds.coef * (a.tile_sums_min[b] + maxint32) * (1.f - 3.814697265625e-06f);
+                    const float gate = bounds.coef * (__int_as_float(ctrl[kLTileMin + bt]) + maxint32) * (1.f - 3.814697265625e-06f);
                     here.pre = gate > bounds.pre ? gate : bounds.pre;
                 }
                 pending_mass = __int_as_float(ctrl[kLMass]);
@@ -942,7 +1001,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
             // ---- exact evaluation.  Scratch lives in the (all-zero) score tile:
             //   hit masks   uint32[m][4]  (bit j = row is in the posting list of query column j)
             //   exact value float64[m]    at byte offset 32768
-            uint32_t *hit_mask = reinterpret_cast<uint32_t *>(scores);
+            uint32_t *hit_mask = iscores;
             double *exact_jaccard = reinterpret_cast<double *>(lds + 32768);
             for (int p = tid; p < m * n; p += kThreads) {  // one (candidate, column) membership test per thread
                 const int i = p / n, j = p - i * n;
@@ -953,8 +1012,8 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                     const uint32_t *words = reinterpret_cast<const uint32_t *>(a.signature + t);
                     hit = (words[sig_bit[j] >> 5] >> (sig_bit[j] & 31)) & 1u;  // exact membership bit of a dense column
                 } else {
-                    const int32_t tile = t >> kTileLog2;
-                    const uint32_t local = static_cast<uint32_t>(t & (kTile - 1));
+                    const int32_t tile = t / kTile;
+                    const uint32_t local = static_cast<uint32_t>(t - tile * kTile);
                     const uint32_t *ptr = a.col_ptr + static_cast<int64_t>(cols[j]) * ptr_stride + tile;
                     uint32_t lo = ptr[0] * 4u;
                     const uint32_t end = ptr[1] * 4u;
@@ -1033,25 +1092,26 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_topk_kernel(JaccardArgs a
                 a.slow_list[atomicAdd(&a.control[kCtlSlowCount], 1)] = static_cast<int32_t>(q);
                 if (reason >= 0) atomicAdd(&a.control[kCtlReason + reason], 1);
             }
-            for (int i = tid * 4; i < kScoreFloats; i += kThreads * 4)
-                *reinterpret_cast<float4 *>(&scores[i]) = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = tid * 4; i < kScoreWords; i += kThreads * 4)
+                *reinterpret_cast<uint4 *>(&iscores[i]) = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();
             DS_STAMP(0);
         }
     }
     if (a.phase != nullptr && tid == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&a.phase[i], phase_lds[i]);
+        for (int i = 0; i < 16; ++i) atomicAdd(&a.phase[i], phase_lds[i]);
 }
 
 // ---- the literal algorithm for the queries the fast kernel hands over ------------------------------------------------
-constexpr int kDenseLdsBytes = kScoreFloats * 4 + 256 * 4 + 64 + (kThreads / 64) * 4;
+constexpr int kDenseScoreFloats = kTile + 64;  // float32 score tile + trash slot
+constexpr int kDenseLdsBytes = kDenseScoreFloats * 4 + 256 * 4 + 64 + (kDenseThreads / 64) * 4;
 
-__global__ __launch_bounds__(kThreads) void ds_jaccard_dense_kernel(JaccardArgs a)
+__global__ __launch_bounds__(kDenseThreads) void ds_jaccard_dense_kernel(JaccardArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     float *scores = reinterpret_cast<float *>(lds);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(lds + kScoreFloats * 4);
-    volatile int32_t *ctrl = reinterpret_cast<volatile int32_t *>(lds + kScoreFloats * 4 + 1024);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds + kDenseScoreFloats * 4);
+    volatile int32_t *ctrl = reinterpret_cast<volatile int32_t *>(lds + kDenseScoreFloats * 4 + 1024);
     int32_t *wave_counts = const_cast<int32_t *>(ctrl) + 16;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1073,7 +1133,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_dense_kernel(JaccardArgs 
         const double maxint = a.q_maxint[q];
 
         bool bad = false;
-        for (int64_t j = tid; j < n; j += kThreads) {
+        for (int64_t j = tid; j < n; j += kDenseThreads) {
             const int32_t column = a.q_cols[qbase + j];
             bad |= column < 0 || column >= a.n_columns;
         }
@@ -1082,27 +1142,27 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_dense_kernel(JaccardArgs 
                 a.status[q] = kQueryErrorArg;
                 atomicAdd(&a.control[kCtlErrors], 1);
             }
-            for (int j = tid; j < k; j += kThreads) a.out_rows[q * k + j] = -1;
+            for (int j = tid; j < k; j += kDenseThreads) a.out_rows[q * k + j] = -1;
             continue;
         }
 
         // fast_jaccard, tile by tile: ordered float32 accumulation (a barrier between two columns), float64 finalise
         for (int b = 0; b < a.n_tiles; ++b) {
-            for (int i = tid; i < kScoreFloats; i += kThreads) scores[i] = 0.f;
+            for (int i = tid; i < kDenseScoreFloats; i += kDenseThreads) scores[i] = 0.f;
             __syncthreads();
             for (int64_t j = 0; j < n; ++j) {
                 const int32_t column = a.q_cols[qbase + j];
                 const float value = a.idf32[column];
                 const uint32_t *ptr = a.col_ptr + static_cast<int64_t>(column) * ptr_stride + b;
                 const uint32_t begin = ptr[0] * 4u, end = ptr[1] * 4u;
-                for (uint32_t i = begin + tid; i < end; i += kThreads) {
+                for (uint32_t i = begin + tid; i < end; i += kDenseThreads) {
                     const uint32_t local = a.postings[i];
                     if (local < kTile) scores[local] = scores[local] + value;  // each row at most once per list
                 }
                 __syncthreads();
             }
-            const int64_t tile_base = static_cast<int64_t>(b) << kTileLog2;
-            for (int i = tid; i < kTile && tile_base + i < n_truth; i += kThreads) {
+            const int64_t tile_base = static_cast<int64_t>(b) * kTile;
+            for (int i = tid; i < kTile && tile_base + i < n_truth; i += kDenseThreads) {
                 const double s = static_cast<double>(scores[i]);
                 jaccard[tile_base + i] = s / (static_cast<double>(a.sums32[tile_base + i]) + (maxint - s));
             }
@@ -1117,7 +1177,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_dense_kernel(JaccardArgs 
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
-            for (int64_t t = tid; t < n_truth; t += kThreads) {
+            for (int64_t t = tid; t < n_truth; t += kDenseThreads) {
                 const double v = jaccard[t];
                 const uint32_t key = v > 0.0 ? __float_as_uint(static_cast<float>(v)) : 0u;
                 if (key != 0u && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
@@ -1145,14 +1205,14 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_dense_kernel(JaccardArgs 
 
         // (array >= threshold).nonzero()[0][::-1][:k]
         int found = 0;
-        for (int64_t top = n_truth - 1; top >= 0 && found < k; top -= kThreads) {
+        for (int64_t top = n_truth - 1; top >= 0 && found < k; top -= kDenseThreads) {
             const int64_t t = top - tid;
             const bool pass = t >= 0 && jaccard[t] >= threshold;
             const unsigned long long votes = __ballot(pass);
             if (lane == 0) wave_counts[wave] = __popcll(votes);
             __syncthreads();
             int before = 0, total = 0;
-            for (int w = 0; w < kThreads / 64; ++w) {
+            for (int w = 0; w < kDenseThreads / 64; ++w) {
                 const int c = wave_counts[w];
                 before += w < wave ? c : 0;
                 total += c;
@@ -1165,7 +1225,7 @@ __global__ __launch_bounds__(kThreads) void ds_jaccard_dense_kernel(JaccardArgs 
             __syncthreads();
         }
         if (found < k) {
-            for (int j = found + tid; j < k; j += kThreads) a.out_rows[q * k + j] = -1;
+            for (int j = found + tid; j < k; j += kDenseThreads) a.out_rows[q * k + j] = -1;
             if (tid == 0) {
                 a.status[q] = kQueryErrorTopN;
                 atomicAdd(&a.control[kCtlErrors], 1);
@@ -1240,13 +1300,13 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     if (const char *debug = getenv("DS_DEBUG"); debug != nullptr) args.debug = atoi(debug);
     if (const char *batch = getenv("DS_REFINE_BATCH"); batch != nullptr) args.refine_batch = atoi(batch);
 
-    const int grid = static_cast<int>(std::min<int64_t>(Q, index->compute_units));
+    const int grid = static_cast<int>(std::min<int64_t>(Q, int64_t(index->compute_units) * kWorkgroupsPerCu));
     DS_HIP(hipMemsetAsync(index->control.ptr, 0, kControlWords * sizeof(int32_t), stream));
     DS_HIP(hipEventRecord(index->event_begin, stream));
     hipLaunchKernelGGL(ds_jaccard_topk_kernel, dim3(grid), dim3(kThreads), kFastLdsBytes, stream, args);
     DS_HIP(hipGetLastError());
     DS_HIP(hipEventRecord(index->event_fast, stream));
-    hipLaunchKernelGGL(ds_jaccard_dense_kernel, dim3(index->slow_slots), dim3(kThreads), kDenseLdsBytes, stream, args);
+    hipLaunchKernelGGL(ds_jaccard_dense_kernel, dim3(index->slow_slots), dim3(kDenseThreads), kDenseLdsBytes, stream, args);
     DS_HIP(hipGetLastError());
     DS_HIP(hipEventRecord(index->event_dense, stream));
     return DS_OK;
@@ -1259,6 +1319,13 @@ static int collect(ds_index *index, hipStream_t stream, int64_t stats[32])
     int32_t control[kControlWords] = {0};
     DS_HIP(hipMemcpyAsync(control, index->control.ptr, sizeof(control), hipMemcpyDeviceToHost, stream));
     DS_HIP(hipStreamSynchronize(stream));
+    if (index->phase.ptr != nullptr && getenv("DS_PHASE_DUMP") != nullptr) {
+        unsigned long long phase[16] = {0};
+        DS_HIP(hipMemcpy(phase, index->phase.ptr, sizeof(phase), hipMemcpyDeviceToHost));
+        fprintf(stderr, "phase cycles:");
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %d=%llu", i, phase[i]);
+        fprintf(stderr, "\n");
+    }
     if (stats) {
         stats[0] = control[kCtlSlowCount];
         stats[1] = control[kCtlErrors];

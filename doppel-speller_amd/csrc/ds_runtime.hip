@@ -85,7 +85,7 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
                        "ds_index_create: posting list of column %lld is not strictly ascending within [0, N)",
                        (long long)g);
             previous = t;
-            ++row[t >> ds::kTileLog2];
+            ++row[t / ds::kTile];
         }
         for (int64_t b = 0; b < n_tiles; ++b) {
             const uint32_t count = row[b];
@@ -98,7 +98,7 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     float sums_min = sums32[0];
     std::vector<float> tile_sums_min(static_cast<size_t>(n_tiles), 0.f);
     for (int64_t b = 0; b < n_tiles; ++b) {
-        const int64_t first = b << ds::kTileLog2, last = std::min<int64_t>(N, first + ds::kTile);
+        const int64_t first = b * ds::kTile, last = std::min<int64_t>(N, first + ds::kTile);
         float lowest = sums32[first];
         for (int64_t t = first + 1; t < last; ++t) lowest = std::min(lowest, sums32[t]);
         tile_sums_min[static_cast<size_t>(b)] = lowest;
@@ -134,14 +134,14 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
         uint64_t write = 0;
         for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
             const int64_t t = truth_idx[p];
-            const int64_t b = t >> ds::kTileLog2;
+            const int64_t b = t / ds::kTile;
             if (b != current_tile) {
                 current_tile = b;
                 write = static_cast<uint64_t>(row[b]) * 4u;
             }
             posting_sums[write] = static_cast<uint16_t>((ds::encode_sums8(sums32[t]) << 8) |
                                                          (signature[static_cast<size_t>(t) * ds::kSignatureWords] & 0xffu));
-            postings[write++] = static_cast<uint16_t>(t & (ds::kTile - 1));
+            postings[write++] = static_cast<uint16_t>(t % ds::kTile);
         }
     }
     DS_HIP(hipSetDevice(device));
@@ -162,8 +162,8 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     if (status == DS_OK) status = index->posting_sums.upload(posting_sums.data(), posting_sums.size());
     if (status == DS_OK && posting_sums.empty()) status = index->posting_sums.allocate(4);
     if (status == DS_OK) status = index->idf32.upload(idf32, static_cast<size_t>(V));
-    if (status == DS_OK) {  // padded so that the dense scan may read four rows at once near the end
-        std::vector<float> padded(static_cast<size_t>(N) + 4, 0.f);
+    if (status == DS_OK) {  // padded so that the dense scan may read eight rows at once near the end
+        std::vector<float> padded(static_cast<size_t>(N) + 8, 0.f);
         std::memcpy(padded.data(), sums32, sizeof(float) * static_cast<size_t>(N));
         status = index->sums32.upload(padded.data(), padded.size());
     }

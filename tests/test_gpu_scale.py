@@ -17,7 +17,8 @@ def test_many_tiles_top50_against_oracle(oracle, big_workload):
     w = big_workload
     k = 50
     pipeline = ds.CandidatePipeline(w, k)
-    assert pipeline.index.info()["tiles"] == 37
+    info = pipeline.index.info()
+    assert info["tiles"] == -(-w.n_truth // info["tile_rows"]) and info["tiles"] > 32  # several list-pointer blocks
     pipeline.step()
     stats = pipeline.sync()
     assert stats["error_queries"] == 0
