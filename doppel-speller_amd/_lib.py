@@ -14,7 +14,8 @@ class DoppelError(Exception):
 
 
 def library_path():
-    return os.path.join(_HERE, "libdoppel_amd.so")
+    # DS_LIBRARY selects another build of the same sources (tuning sweeps: scripts/sweep_variants.sh)
+    return os.environ.get("DS_LIBRARY") or os.path.join(_HERE, "libdoppel_amd.so")
 
 
 def build_library(force=False, verbose=False):

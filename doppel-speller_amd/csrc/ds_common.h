@@ -34,7 +34,7 @@ constexpr int kDenseThreads = 1024;          // literal kernel: one 16-wave work
 static_assert(kTile % 4096 == 0 && kTile < 65536, "tile rows: whole scan iterations, 16-bit local indexes");
 constexpr int kMaxQueryColumns = 128;        // fast-path limit (example data: p99 50, max 96 tri-grams per title)
 constexpr int kCandidates = DS_CANDIDATES;            // capacity of the per-query candidate buffer in LDS
-constexpr int kLooseStep = 512;              // rows scanned between two capacity checks while no threshold exists
+constexpr int kLooseStep = 256;              // rows scanned between two capacity checks while no threshold exists
 constexpr int kPtrTiles = DS_PTR_TILES;                 // tiles whose list pointers are cached in LDS at a time
 constexpr int kItemQuads = 256;              // a work item = up to 256 posting quads of one (tile, column) list
 constexpr int kMaxItems = 512;               // work items per (query, tile); more => dense kernel

@@ -97,17 +97,27 @@ constexpr int kKeep = (kCandidates + kThreads - 1) / kThreads;  // candidate ent
 constexpr int kSelectTrigger = kCandidates - kLooseStep;
 constexpr int kWaves = kThreads / 64;
 #ifndef DS_SCAN_BATCH
-#define DS_SCAN_BATCH 2
+#define DS_SCAN_BATCH 1
 #endif
 constexpr float kFixedOne = 65000.f;  // fixed-point value of the query's total IDF mass (+ n <= 128 roundings < 2^16)
 constexpr int kProbeMaxK = kThreads / 4;  // threshold bootstrap from per-thread samples: k well below the sample count
-constexpr int kUnits = 2;  // chunks of 4 quads per lane in flight per wave (register budget)
+#ifndef DS_UNITS
+#define DS_UNITS 1
+#endif
+constexpr int kUnits = DS_UNITS;  // chunks of 4 quads per lane in flight per wave (register budget)
 
 // LDS control words
 enum { kLQuery = 0, kLCount, kLOverflow, kLDigit, kLRemain, kLCoef, kLPre, kLCut, kLKth0, kLKth1, kLBad, kLItems,
        kLQuads, kLNonEssential, kLMass, kLSparse, kLSigMask /* 4 words */, kLEnd = kLSigMask + 4,
        kLTileMin = 24 /* kPtrTiles floats: min sums32 of the cached tiles */ };
 static_assert(kLEnd <= kLTileMin && kLTileMin + kPtrTiles <= 32, "LDS control words");
+
+// Workgroup-uniform values read from LDS or computed on the vector ALU live in VGPRs unless the compiler is told that
+// they are uniform: `uniform` moves them to scalar registers (the kernel is VGPR-bound: 128 per lane at 2 WGs/CU).
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
+__device__ __forceinline__ float uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ bool uniform(bool v) { return __builtin_amdgcn_readfirstlane(v ? 1 : 0) != 0; }
 
 __device__ __forceinline__ float round_down_positive(double x)
 {
@@ -167,9 +177,9 @@ __device__ uint32_t radix_select_kth(const uint32_t *keys, int m, int k, uint32_
             }
         }
         __syncthreads();
-        prefix |= static_cast<uint32_t>(ctrl[kLDigit]) << shift;
+        prefix |= static_cast<uint32_t>(uniform(static_cast<int>(ctrl[kLDigit]))) << shift;
         mask |= 255u << shift;
-        remaining = ctrl[kLRemain];
+        remaining = uniform(static_cast<int>(ctrl[kLRemain]));
     }
     return prefix;
 }
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             ctrl[kLBad] = 0;
         }
         __syncthreads();
-        const int64_t q = ctrl[kLQuery];
+        const int64_t q = uniform(static_cast<int>(ctrl[kLQuery]));
         if (q >= a.n_queries) break;  // exit condition reached by every wave: the queue head only grows
 
         const int64_t qbase = a.q_rowptr[q];
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             if (bit >= 0) bit_idf[bit] = value;
         }
         __syncthreads();
-        if (ctrl[kLBad]) {
+        if (uniform(static_cast<int>(ctrl[kLBad]))) {
             if (tid == 0) {
                 a.status[q] = kQueryErrorArg;
                 atomicAdd(&a.control[kCtlErrors], 1);
@@ -391,12 +401,12 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
         // faster than ds_add_f32 on gfx950 and are order-independent): one unit = total/kFixedOne where total >=
         // every reachable score.  A row's sum is at most kFixedOne + n (every term rounds by < 1 unit) < 65536, so
         // the low half of a word never carries into the high half.
-        const float total_mass = n > 0 ? fmaxf(maxint32, mass_upto[n - 1]) : maxint32;
-        const float to_fixed = kFixedOne / total_mass, from_fixed = total_mass * (1.f / kFixedOne);
+        const float total_mass = uniform(n > 0 ? fmaxf(maxint32, mass_upto[n - 1]) : maxint32);
+        const float to_fixed = uniform(kFixedOne / total_mass), from_fixed = uniform(total_mass * (1.f / kFixedOne));
         if (tid < n) fixed[tid] = max(1u, static_cast<uint32_t>(idf[tid] * to_fixed + 0.5f));
         // |approximate jaccard - exact jaccard| <= margin (DESIGN.md "error margin of the prefilter"):
         // float32 evaluation + quantisation of n terms to one unit each (4 = bound of d jaccard / d score * total)
-        const double margin = (6.0 * n + 64.0) * 5.9604644775390625e-08 + n * (4.0 / kFixedOne) * 1.001;
+        auto error_margin = [&]() { return (6.0 * n + 64.0) * 5.9604644775390625e-08 + n * (4.0 / kFixedOne) * 1.001; };
         Bounds bounds{0.f, FLT_MIN, 0.f, maxint32};
         float cut = 0.f, pending_mass = 0.f;  // mass of the columns skipped from the NEXT tile on
         uint32_t pending_sig_mask[kSignatureWords] = {0u, 0u, 0u, 0u};
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
         // or drops them.  Deferred until enough raw entries exist; always runs before a selection, so every raw
         // entry was produced under the current `skipped` set.  Called by all threads after a barrier; ends with one.
         auto refine = [&]() {
-            const int last_raw = min(static_cast<int>(ctrl[kLCount]), kCandidates);
+            const int last_raw = uniform(min(static_cast<int>(ctrl[kLCount]), kCandidates));
             if (last_raw <= first_raw) return;
             DS_STAMP(10);
             if (tid == 0 && a.phase != nullptr) {
@@ -460,13 +470,13 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             }
             __syncthreads();
             if (tid == 0 && a.phase != nullptr) atomicAdd(&a.control[kCtlSurvivors], ctrl[kLCount] - first_raw);
-            first_raw = ctrl[kLCount];
+            first_raw = uniform(static_cast<int>(ctrl[kLCount]));
             __syncthreads();  // every thread holds the same count before anything is appended again
             DS_STAMP(8);
         };
         // refine when raw entries pile up, when a selection is due, or when the buffer runs short of room
         auto refine_due = [&]() {
-            const int count = ctrl[kLCount];
+            const int count = uniform(static_cast<int>(ctrl[kLCount]));
             return count - first_raw >= refine_batch || count > kCandidates - kRefineRoom;
         };
 
@@ -505,7 +515,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             if (bt == kPtrTiles - 1 && b + 1 < a.n_tiles) prefetch(b + 1);
             // ---- work items of this tile: (column, chunk of kItemQuads quads) for every essential column
             // raw entries were scored under the current set of skipped columns: refine them before it changes
-            if (non_essential != skipped.count && first_raw != ctrl[kLCount]) refine();
+            if (non_essential != skipped.count && first_raw != uniform(static_cast<int>(ctrl[kLCount]))) refine();
             bounds.mass = pending_mass;  // what this tile's scores do NOT contain; fixed until the tile is done
             skipped.count = non_essential;
             for (int w = 0; w < kSignatureWords; ++w) skipped.sig_mask[w] = pending_sig_mask[w];
@@ -556,17 +566,17 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     if (lane == 0) ctrl[kLItems] = static_cast<int32_t>(total0 + total1);
                 }
                 __syncthreads();
-                n_items = ctrl[kLItems];
+                n_items = uniform(static_cast<int>(ctrl[kLItems]));
             }
             DS_STAMP(1);
 
             const int64_t tile_base = static_cast<int64_t>(b) * kTile;
             // read here, where a barrier (end of the scatter) separates every thread's read from the next append
-            int count_at_step = ctrl[kLCount];
+            int count_at_step = uniform(static_cast<int>(ctrl[kLCount]));
             // row-independent gate of this tile: coef * (min sums of the tile + maxint), rounded down
             Bounds here = bounds;
             {
-                const float gate = bounds.coef * (__int_as_float(ctrl[kLTileMin + bt]) + maxint32) * (1.f - 3.814697265625e-06f);
+                const float gate = uniform(bounds.coef * (__int_as_float(ctrl[kLTileMin + bt]) + maxint32) * (1.f - 3.814697265625e-06f));
                 if (gate > here.pre) here.pre = gate;
             }
             // A sweep only runs the register-level tests and appends RAW entries (approximate essential score, row);
@@ -594,7 +604,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 // lane to reach a row takes its score and leaves zero behind.  Two chunks (8 quads per lane) are in
                 // flight at a time.
                 ++sparse_tiles;
-                const int count_before = ctrl[kLCount];
+                const int count_before = uniform(static_cast<int>(ctrl[kLCount]));
 #pragma unroll 1
                 for (int sweep = 0; sweep < 2; ++sweep) {
                     int j = (a.debug & 1) ? n : wave;
@@ -606,12 +616,12 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                         for (int h = 0; h < kUnits; ++h) {
                             first[h] = last[h] = value[h] = 0u;
                             while (j < n) {
-                                const uint32_t begin = ptr_cache[j * (kPtrTiles + 1) + bt] + position;
-                                const uint32_t end = ptr_cache[j * (kPtrTiles + 1) + bt + 1];
-                                if (rank[j] >= non_essential && begin < end) {
+                                const uint32_t begin = uniform(ptr_cache[j * (kPtrTiles + 1) + bt]) + position;
+                                const uint32_t end = uniform(ptr_cache[j * (kPtrTiles + 1) + bt + 1]);
+                                if (uniform(rank[j]) >= non_essential && begin < end) {
                                     first[h] = begin;
                                     last[h] = end;
-                                    value[h] = fixed[j];
+                                    value[h] = uniform(fixed[j]);
                                     position += kItemQuads;
                                     ++units;
                                     break;
@@ -670,7 +680,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     __syncthreads();
                     DS_STAMP(sweep == 0 ? 6 : 7);
                 }
-                if (ctrl[kLOverflow]) { slow = true; reason = 2; break; }
+                if (uniform(static_cast<int>(ctrl[kLOverflow]))) { slow = true; reason = 2; break; }
                 if (tid == 0 && a.phase != nullptr) atomicAdd(&a.control[kCtlRawSparse], ctrl[kLCount] - count_before);
                 if (refine_due()) refine();
             } else {
@@ -688,9 +698,9 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                         const int before = __popcll(__ballot(item_first[lane] <= want)) +
                                            __popcll(__ballot(item_first[lane + 64] <= want));
                         const int j = item_ok ? before - 1 : 0;
-                        const uint32_t first = list_begin[j] + (want - item_first[j]) * kItemQuads + lane;
-                        const uint32_t end = item_ok ? list_end[j] : 0u;
-                        value[h] = fixed[j];
+                        const uint32_t first = uniform(list_begin[j] + (want - item_first[j]) * kItemQuads) + lane;
+                        const uint32_t end = item_ok ? uniform(list_end[j]) : 0u;
+                        value[h] = uniform(fixed[j]);
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const uint32_t index = first + u * 64;
@@ -718,7 +728,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             const int limit = rows_left >= kTile ? kTile : static_cast<int>((rows_left + 7) & ~int64_t(7));
             int r0 = sparse ? limit : 0;
             if (!sparse) ++dense_tiles;
-            bool select_now = sparse && first_raw == ctrl[kLCount] && ctrl[kLCount] >= next_select;
+            bool select_now = sparse && uniform(first_raw == ctrl[kLCount] && ctrl[kLCount] >= next_select);
             int retries = 0;
             bool probed = false;
             int32_t drop_lo = 0, drop_hi = 0;  // rows to drop at the next pruning (a step that is scanned again)
@@ -820,8 +830,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     }
                     __syncthreads();
                     DS_STAMP(3);
-                    last_appended = ctrl[kLCount] - count_at_step;
-                    if (ctrl[kLOverflow]) {
+                    last_appended = uniform(static_cast<int>(ctrl[kLCount])) - count_at_step;
+                    if (uniform(static_cast<int>(ctrl[kLOverflow]))) {
                         // the buffer holds as many of the step's rows as fitted: refine them, tighten the threshold
                         // with them, drop the step's rows from the buffer and scan the same rows again
                         if (!recoverable || ++retries > 4) { slow = true; reason = 3; break; }
@@ -849,7 +859,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     DS_STAMP(12);
                 }
                 select_now = false;
-                const int m = ctrl[kLCount];
+                const int m = uniform(static_cast<int>(ctrl[kLCount]));
                 // raw entries are refined before any selection
                 if ((m < next_select && !force_select) || first_raw != m || m < k) {
                     if (force_select) { slow = true; reason = 3; break; }  // nothing to tighten with
@@ -860,7 +870,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 ++selects;
                 if (wave == 0) {
                     const double tau = static_cast<double>(__uint_as_float(tau_key));
-                    const double cut_value = tau - 2.0 * margin - 2e-6;
+                    const double cut_value = tau - 2.0 * error_margin() - 2e-6;
                     float new_coef = 0.f, new_pre = FLT_MIN, new_cut = 0.f;
                     if (tau_key < 0x7f800000u && cut_value > 0.0) {
                         const double c = cut_value / (1.0 + cut_value) * (1.0 - 9.5367431640625e-07);
@@ -914,19 +924,19 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     }
                 }
                 __syncthreads();
-                bounds.coef = __int_as_float(ctrl[kLCoef]);
-                bounds.pre = __int_as_float(ctrl[kLPre]);
+                bounds.coef = uniform(__int_as_float(ctrl[kLCoef]));
+                bounds.pre = uniform(__int_as_float(ctrl[kLPre]));
                 here.coef = bounds.coef;
                 {
-                    const float gate = bounds.coef * (__int_as_float(ctrl[kLTileMin + bt]) + maxint32) * (1.f - 3.814697265625e-06f);
+                    const float gate = uniform(bounds.coef * (__int_as_float(ctrl[kLTileMin + bt]) + maxint32) * (1.f - 3.814697265625e-06f));
                     here.pre = gate > bounds.pre ? gate : bounds.pre;
                 }
-                pending_mass = __int_as_float(ctrl[kLMass]);
+                pending_mass = uniform(__int_as_float(ctrl[kLMass]));
                 rebuild_mass_table = true;
-                for (int w = 0; w < kSignatureWords; ++w) pending_sig_mask[w] = static_cast<uint32_t>(ctrl[kLSigMask + w]);
-                cut = __int_as_float(ctrl[kLCut]);
-                non_essential = ctrl[kLNonEssential];
-                sparse_mode = ctrl[kLSparse] != 0;
+                for (int w = 0; w < kSignatureWords; ++w) pending_sig_mask[w] = uniform(static_cast<uint32_t>(ctrl[kLSigMask + w]));
+                cut = uniform(__int_as_float(ctrl[kLCut]));
+                non_essential = uniform(static_cast<int>(ctrl[kLNonEssential]));
+                sparse_mode = uniform(static_cast<int>(ctrl[kLSparse])) != 0;
                 tight = true;
                 // in-place compaction: read everything, barrier, rewrite the survivors
                 uint32_t keep_key[kKeep];
@@ -951,7 +961,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 }
                 drop_lo = drop_hi = 0;
                 __syncthreads();
-                const int kept = ctrl[kLCount];
+                const int kept = uniform(static_cast<int>(ctrl[kLCount]));
                 __syncthreads();  // a retried scan appends right away: the count must be read by all threads first
                 if (kept > kSelectTrigger) { slow = true; reason = 4; break; }  // massive ties: use the dense kernel
                 next_select = min(kSelectTrigger, max(2 * kept, max(4 * k, 64)));
@@ -965,7 +975,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             __syncthreads();
             refine();
         }
-        int m = slow ? 0 : ctrl[kLCount];
+        int m = slow ? 0 : uniform(static_cast<int>(ctrl[kLCount]));
         if (!slow && m < k) { slow = true; reason = 5; }  // fewer than k positive rows: literal path decides
         if (!slow) {
             // final tightening so that only k + near-ties + margin survivors are evaluated exactly
@@ -973,7 +983,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 const uint32_t tau_key = radix_select_kth(cand_key, m, k, hist, ctrl, 4);
                 ++selects;
                 const double tau = static_cast<double>(__uint_as_float(tau_key));
-                const double cut_value = tau - 2.0 * margin - 2e-6;
+                const double cut_value = tau - 2.0 * error_margin() - 2e-6;
                 const float final_cut =
                     (tau_key < 0x7f800000u && cut_value > 0.0) ? round_down_positive(cut_value) : 0.f;
                 uint32_t keep_key[kKeep];
@@ -995,7 +1005,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     }
                 }
                 __syncthreads();
-                m = ctrl[kLCount];
+                m = uniform(static_cast<int>(ctrl[kLCount]));
             }
             DS_STAMP(4);
             // ---- exact evaluation.  Scratch lives in the (all-zero) score tile:
