@@ -81,11 +81,8 @@ constexpr int kOffBitIdf = kOffSigBit + kMaxQueryColumns * 4;
 constexpr int kOffFixed = kOffBitIdf + kSignatureBits * 4;
 constexpr int kOffTotal = kOffFixed + kMaxQueryColumns * 4;
 constexpr int kOffMassTable = kOffTotal + kMaxQueryColumns * 4;
-constexpr int kOffBegin = kOffMassTable + 256 * 4;
-constexpr int kOffEnd = kOffBegin + kMaxQueryColumns * 4;
-constexpr int kOffPtr = kOffEnd + kMaxQueryColumns * 4;
-constexpr int kOffItems = kOffPtr + kMaxQueryColumns * (kPtrTiles + 1) * 4;
-constexpr int kOffHist = kOffItems + kMaxQueryColumns * 4;
+constexpr int kOffPtr = kOffMassTable + 256 * 4;
+constexpr int kOffHist = kOffPtr + kMaxQueryColumns * (kPtrTiles + 1) * 4;
 constexpr int kOffCtrl = kOffHist + 256 * 4;
 constexpr int kFastLdsBytes = kOffCtrl + 128;
 static_assert((kFastLdsBytes + 256) * kWorkgroupsPerCu <= 160 * 1024, "LDS budget of one CU exceeded");
@@ -101,10 +98,6 @@ constexpr int kWaves = kThreads / 64;
 #endif
 constexpr float kFixedOne = 65000.f;  // fixed-point value of the query's total IDF mass (+ n <= 128 roundings < 2^16)
 constexpr int kProbeMaxK = kThreads / 4;  // threshold bootstrap from per-thread samples: k well below the sample count
-#ifndef DS_UNITS
-#define DS_UNITS 1
-#endif
-constexpr int kUnits = DS_UNITS;  // chunks of 4 quads per lane in flight per wave (register budget)
 
 // LDS control words
 enum { kLQuery = 0, kLCount, kLOverflow, kLDigit, kLRemain, kLCoef, kLPre, kLCut, kLKth0, kLKth1, kLBad, kLItems,
@@ -321,10 +314,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
     uint32_t *col_total = reinterpret_cast<uint32_t *>(lds + kOffTotal);  // quads of column j over all tiles
     // mass_table[b] = upper bound of what the skipped columns add to a row whose signature bits 0..7 are b
     float *mass_table = reinterpret_cast<float *>(lds + kOffMassTable);
-    uint32_t *list_begin = reinterpret_cast<uint32_t *>(lds + kOffBegin);
-    uint32_t *list_end = reinterpret_cast<uint32_t *>(lds + kOffEnd);
     uint32_t *ptr_cache = reinterpret_cast<uint32_t *>(lds + kOffPtr);  // [column][kPtrTiles + 1]
-    uint32_t *item_first = reinterpret_cast<uint32_t *>(lds + kOffItems);  // [column] work items before column j
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + kOffHist);
     volatile int32_t *ctrl = reinterpret_cast<volatile int32_t *>(lds + kOffCtrl);
 
@@ -447,6 +437,21 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     if (!DS_OK_INDEX(1, t, a.n_truth)) continue;
                     const float sums = a.sums32[t];
                     const uint4 signature = skipped.count > 0 ? a.signature[t] : make_uint4(0u, 0u, 0u, 0u);
+                    if (a.phase != nullptr && (a.debug & 32)) {
+                        // diagnostics: would knowing only the first G signature bits of the row have rejected it?
+                        const uint32_t words[4] = {signature.x, signature.y, signature.z, signature.w};
+                        float lacking = 0.f;
+                        int slot = 20;
+                        for (int g = 0; g < kSignatureBits; ++g) {
+                            if (((skipped.sig_mask[g >> 5] >> (g & 31)) & 1u) && !((words[g >> 5] >> (g & 31)) & 1u))
+                                lacking += bit_idf[g];
+                            if (g == 7 || g == 15 || g == 31 || g == 127) {
+                                if (!(raw + (bounds.mass - lacking) * 1.0001f >= bounds.coef * (sums + bounds.maxint32)))
+                                    atomicAdd(&a.control[slot], 1);
+                                ++slot;
+                            }
+                        }
+                    }
                     if (may_qualify(raw, sums, bounds)) {
                         const float full = complete_score(raw, signature, skipped, bit_idf);
                         uint32_t key = 0;
@@ -513,7 +518,6 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 __syncthreads();
             }
             if (bt == kPtrTiles - 1 && b + 1 < a.n_tiles) prefetch(b + 1);
-            // ---- work items of this tile: (column, chunk of kItemQuads quads) for every essential column
             // raw entries were scored under the current set of skipped columns: refine them before it changes
             if (non_essential != skipped.count && first_raw != uniform(static_cast<int>(ctrl[kLCount]))) refine();
             bounds.mass = pending_mass;  // what this tile's scores do NOT contain; fixed until the tile is done
@@ -536,38 +540,54 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 }
             }
             const bool sparse = tight && sparse_mode;
-            int n_items = 0;
-            if (!sparse) {
-                if (wave == 0) {
-                    // item_first[j] = number of 256-quad work items of the columns before j (exclusive scan); a wave
-                    // finds the column of item `it` as the last j with item_first[j] <= it (two ballots)
-                    uint32_t count[2];
+            // ---- work items of this tile: (essential column, chunk of 64 quads).  Every wave computes the same
+            // exclusive prefix of the per-column item counts in registers (lane j: columns j and j + 64), so that no
+            // barrier and no LDS table is needed; item `at` belongs to the last column whose prefix is <= at.
+            uint32_t list_first[2], list_quads[2], item_before[2];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int j = lane + 64 * h;
-                        uint32_t begin = 0, end = 0;
-                        if (j < n && rank[j] >= non_essential) {
-                            begin = ptr_cache[j * (kPtrTiles + 1) + bt];
-                            end = ptr_cache[j * (kPtrTiles + 1) + bt + 1];
-                        }
-                        list_begin[j] = begin;
-                        list_end[j] = end;
-                        count[h] = (end - begin + kItemQuads - 1) / kItemQuads;
-                    }
-                    const uint32_t scan0 = wave_inclusive_scan(count[0], lane);
-                    const uint32_t total0 = __shfl(scan0, 63);
-                    uint32_t scan1 = 0, total1 = 0;
-                    if (n > 64) {
-                        scan1 = wave_inclusive_scan(count[1], lane);
-                        total1 = __shfl(scan1, 63);
-                    }
-                    item_first[lane] = scan0 - count[0];
-                    item_first[lane + 64] = total0 + scan1 - count[1];
-                    if (lane == 0) ctrl[kLItems] = static_cast<int32_t>(total0 + total1);
+            for (int h = 0; h < 2; ++h) {
+                const int j = lane + 64 * h;
+                uint32_t begin = 0, end = 0;
+                if (j < n && rank[j] >= non_essential) {
+                    begin = ptr_cache[j * (kPtrTiles + 1) + bt];
+                    end = ptr_cache[j * (kPtrTiles + 1) + bt + 1];
                 }
-                __syncthreads();
-                n_items = uniform(static_cast<int>(ctrl[kLItems]));
+                list_first[h] = begin;
+                list_quads[h] = end - begin;
             }
+            int n_items;
+            {
+                const uint32_t count0 = (list_quads[0] + 63u) >> 6, count1 = (list_quads[1] + 63u) >> 6;
+                const uint32_t scan0 = wave_inclusive_scan(count0, lane);
+                const uint32_t total0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(scan0), 63));
+                uint32_t scan1 = 0, total1 = 0;
+                if (n > 64) {
+                    scan1 = wave_inclusive_scan(count1, lane);
+                    total1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(scan1), 63));
+                }
+                item_before[0] = scan0 - count0;
+                item_before[1] = total0 + scan1 - count1;
+                n_items = static_cast<int>(total0 + total1);
+            }
+            // (first quad of this lane, end of the list, fixed-point IDF) of work item `at`
+            auto locate = [&](int at, uint32_t &first, uint32_t &end, uint32_t &value) {
+                const uint32_t want = static_cast<uint32_t>(at);
+                const int before = __popcll(__ballot(item_before[0] <= want)) + __popcll(__ballot(item_before[1] <= want));
+                const int j = before - 1, l = j & 63;
+                uint32_t begin, quads_in_list, prefix;
+                if (j < 64) {
+                    begin = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(list_first[0]), l));
+                    quads_in_list = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(list_quads[0]), l));
+                    prefix = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(item_before[0]), l));
+                } else {
+                    begin = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(list_first[1]), l));
+                    quads_in_list = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(list_quads[1]), l));
+                    prefix = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(item_before[1]), l));
+                }
+                first = begin + (want - prefix) * 64u + lane;
+                end = begin + quads_in_list;
+                value = uniform(fixed[j]);
+            };
             DS_STAMP(1);
 
             const int64_t tile_base = static_cast<int64_t>(b) * kTile;
@@ -598,129 +618,84 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                                      cand_key, cand_row, ctrl, lane);
             };
 
-            if (sparse) {
-                // ---- sparse tile: wave w owns the essential columns w, w + kWaves, ...; no item list, two barriers.
-                // (1s) scatter with fixed-point LDS atomics; (2s) exchange sweep over the same postings: the first
-                // lane to reach a row takes its score and leaves zero behind.  Two chunks (8 quads per lane) are in
-                // flight at a time.
-                ++sparse_tiles;
-                const int count_before = uniform(static_cast<int>(ctrl[kLCount]));
-#pragma unroll 1
-                for (int sweep = 0; sweep < 2; ++sweep) {
-                    int j = (a.debug & 1) ? n : wave;
-                    uint32_t position = 0;
-                    for (;;) {
-                        uint32_t first[kUnits], last[kUnits], value[kUnits];
-                        int units = 0;
+            // ---- (1) scatter: fixed-point LDS atomics; padding entries hit the trash word.  Wave w takes the items
+            // w, w + kWaves, ...: four of them (one quad per lane each) are in flight at a time.  On a sparse tile whose
+            // items fit one round the quads (and their per-posting info) stay in registers for the collect sweep.
+            constexpr int kRound = 4;
+            const bool single_round = sparse && n_items <= kRound * kWaves;
+            uint2 quad[kRound], quad_info[kRound];
+            bool live[kRound] = {false, false, false, false};  // a wave without items still runs the collect sweep
+            const int count_before = count_at_step;
+            for (int round = (sparse && (a.debug & 1)) ? n_items : 0; wave + round * kWaves < n_items; round += kRound) {
+                uint32_t value[kRound];
 #pragma unroll
-                        for (int h = 0; h < kUnits; ++h) {
-                            first[h] = last[h] = value[h] = 0u;
-                            while (j < n) {
-                                const uint32_t begin = uniform(ptr_cache[j * (kPtrTiles + 1) + bt]) + position;
-                                const uint32_t end = uniform(ptr_cache[j * (kPtrTiles + 1) + bt + 1]);
-                                if (uniform(rank[j]) >= non_essential && begin < end) {
-                                    first[h] = begin;
-                                    last[h] = end;
-                                    value[h] = uniform(fixed[j]);
-                                    position += kItemQuads;
-                                    ++units;
-                                    break;
-                                }
-                                j += kWaves;
-                                position = 0;
-                            }
-                        }
-                        if (units == 0) break;
-                        uint2 quad[4 * kUnits], quad_sums[4 * kUnits];
-                        bool live[4 * kUnits];
-#pragma unroll
-                        for (int u = 0; u < 4 * kUnits; ++u) {
-                            const uint32_t index = first[u >> 2] + (u & 3) * 64 + lane;
-                            live[u] = index < last[u >> 2];
-                            live[u] = live[u] && DS_OK_INDEX(3, index, a.n_quads);
-                            quad[u] = live[u] ? quads[index] : make_uint2(kSentinel * 0x10001u, kSentinel * 0x10001u);
-                            if (sweep == 1 && live[u]) quad_sums[u] = sums_quads[index];
-                        }
-                        if (sweep == 0) {
-#pragma unroll
-                            for (int u = 0; u < 4 * kUnits; ++u) {
-                                if (!live[u]) continue;
-                                const uint32_t v = value[u >> 2];
-                                add_packed(iscores, quad[u].x & 0xffffu, v);
-                                add_packed(iscores, quad[u].x >> 16, v);
-                                add_packed(iscores, quad[u].y & 0xffffu, v);
-                                add_packed(iscores, quad[u].y >> 16, v);
-                            }
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < 4 * kUnits; ++u) {
-                                if (__ballot(live[u]) == 0) continue;
-                                const uint32_t local[4] = {quad[u].x & 0xffffu, quad[u].x >> 16, quad[u].y & 0xffffu,
-                                                           quad[u].y >> 16};
-                                const uint32_t info[4] = {quad_sums[u].x & 0xffffu, quad_sums[u].x >> 16,
-                                                          quad_sums[u].y & 0xffffu, quad_sums[u].y >> 16};
-                                uint32_t taken[4];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    taken[e] = (live[u] && local[e] < kTile) ? take_packed(iscores, local[e]) : 0u;
-                                if (!(a.debug & 2)) {
-                                    const float s4[4] = {static_cast<float>(taken[0]) * from_fixed,
-                                                         static_cast<float>(taken[1]) * from_fixed,
-                                                         static_cast<float>(taken[2]) * from_fixed,
-                                                         static_cast<float>(taken[3]) * from_fixed};
-                                    const float bound4[4] = {decode_sums8(info[0] >> 8), decode_sums8(info[1] >> 8),
-                                                             decode_sums8(info[2] >> 8), decode_sums8(info[3] >> 8)};
-                                    const float mass4[4] = {mass_table[info[0] & 0xffu], mass_table[info[1] & 0xffu],
-                                                            mass_table[info[2] & 0xffu], mass_table[info[3] & 0xffu]};
-                                    consider4(s4, local, bound4, mass4);
-                                }
-                            }
-                        }
-                    }
-                    __syncthreads();
-                    DS_STAMP(sweep == 0 ? 6 : 7);
+                for (int u = 0; u < kRound; ++u) {
+                    const int at = wave + (round + u) * kWaves;
+                    uint32_t first = 0, end = 0;
+                    value[u] = 0;
+                    if (at < n_items) locate(at, first, end, value[u]);
+                    live[u] = first < end && DS_OK_INDEX(3, first, a.n_quads);
+                    quad[u] = live[u] ? quads[first] : make_uint2(kSentinel * 0x10001u, kSentinel * 0x10001u);
+                    if (single_round && live[u]) quad_info[u] = sums_quads[first];
                 }
-                if (uniform(static_cast<int>(ctrl[kLOverflow]))) { slow = true; reason = 2; break; }
-                if (tid == 0 && a.phase != nullptr) atomicAdd(&a.control[kCtlRawSparse], ctrl[kLCount] - count_before);
-                if (refine_due()) refine();
-            } else {
-                // ---- dense tile (1) scatter: fixed-point LDS atomics (ds_add_u32); padding entries hit the trash slot
-                // scores[kTile].  A wave owns whole items; two items (up to 8 quad loads per lane) are in flight.
-                for (int it = wave; it < n_items; it += kUnits * kWaves) {
-                    uint2 quad[4 * kUnits];
-                    bool live[4 * kUnits];
-                    uint32_t value[kUnits];
 #pragma unroll
-                    for (int h = 0; h < kUnits; ++h) {
-                        const int at = it + h * kWaves;
-                        const bool item_ok = at < n_items;
-                        const uint32_t want = static_cast<uint32_t>(at);
-                        const int before = __popcll(__ballot(item_first[lane] <= want)) +
-                                           __popcll(__ballot(item_first[lane + 64] <= want));
-                        const int j = item_ok ? before - 1 : 0;
-                        const uint32_t first = uniform(list_begin[j] + (want - item_first[j]) * kItemQuads) + lane;
-                        const uint32_t end = item_ok ? uniform(list_end[j]) : 0u;
-                        value[h] = uniform(fixed[j]);
+                for (int u = 0; u < kRound; ++u) {
+                    if (!live[u]) continue;
+                    add_packed(iscores, quad[u].x & 0xffffu, value[u]);
+                    add_packed(iscores, quad[u].x >> 16, value[u]);
+                    add_packed(iscores, quad[u].y & 0xffffu, value[u]);
+                    add_packed(iscores, quad[u].y >> 16, value[u]);
+                }
+            }
+            __syncthreads();
+            DS_STAMP(sparse ? 6 : 2);
+
+            if (sparse) {
+                // ---- (2s) collect sweep over the same postings: the first lane to reach a row takes its score and
+                // leaves zero behind (no scan of the whole tile)
+                ++sparse_tiles;
+                auto collect = [&]() {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const uint32_t index = first + u * 64;
-                            live[h * 4 + u] = index < end;
-                            live[h * 4 + u] = live[h * 4 + u] && DS_OK_INDEX(4, index, a.n_quads);
-                            if (live[h * 4 + u]) quad[h * 4 + u] = quads[index];
-                        }
+                    for (int u = 0; u < kRound; ++u) {
+                        if (__ballot(live[u]) == 0) continue;
+                        const uint32_t local[4] = {quad[u].x & 0xffffu, quad[u].x >> 16, quad[u].y & 0xffffu, quad[u].y >> 16};
+                        const uint32_t info[4] = {quad_info[u].x & 0xffffu, quad_info[u].x >> 16, quad_info[u].y & 0xffffu,
+                                                  quad_info[u].y >> 16};
+                        uint32_t taken[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            taken[e] = (live[u] && local[e] < kTile) ? take_packed(iscores, local[e]) : 0u;
+                        if (a.debug & 2) continue;
+                        const float s4[4] = {static_cast<float>(taken[0]) * from_fixed, static_cast<float>(taken[1]) * from_fixed,
+                                             static_cast<float>(taken[2]) * from_fixed, static_cast<float>(taken[3]) * from_fixed};
+                        const float bound4[4] = {decode_sums8(info[0] >> 8), decode_sums8(info[1] >> 8),
+                                                 decode_sums8(info[2] >> 8), decode_sums8(info[3] >> 8)};
+                        const float mass4[4] = {mass_table[info[0] & 0xffu], mass_table[info[1] & 0xffu],
+                                                mass_table[info[2] & 0xffu], mass_table[info[3] & 0xffu]};
+                        consider4(s4, local, bound4, mass4);
                     }
+                };
+                if (single_round) {
+                    collect();
+                } else {
+                    for (int round = (a.debug & 1) ? n_items : 0; wave + round * kWaves < n_items; round += kRound) {
 #pragma unroll
-                    for (int u = 0; u < 4 * kUnits; ++u) {
-                        if (!live[u]) continue;
-                        const uint32_t v = value[u >> 2];
-                        add_packed(iscores, quad[u].x & 0xffffu, v);
-                        add_packed(iscores, quad[u].x >> 16, v);
-                        add_packed(iscores, quad[u].y & 0xffffu, v);
-                        add_packed(iscores, quad[u].y >> 16, v);
+                        for (int u = 0; u < kRound; ++u) {
+                            const int at = wave + (round + u) * kWaves;
+                            uint32_t first = 0, end = 0, value = 0;
+                            if (at < n_items) locate(at, first, end, value);
+                            live[u] = first < end && DS_OK_INDEX(3, first, a.n_quads);
+                            quad[u] = live[u] ? quads[first] : make_uint2(kSentinel * 0x10001u, kSentinel * 0x10001u);
+                            if (live[u]) quad_info[u] = sums_quads[first];
+                        }
+                        collect();
                     }
                 }
                 __syncthreads();
-                DS_STAMP(2);
+                DS_STAMP(7);
+                if (uniform(static_cast<int>(ctrl[kLOverflow]))) { slow = true; reason = 2; break; }
+                if (tid == 0 && a.phase != nullptr) atomicAdd(&a.control[kCtlRawSparse], ctrl[kLCount] - count_before);
+                if (refine_due()) refine();
             }
 
             // ---- (2d) dense scan (and re-zero) of the tile; in steps while no running value exists
@@ -1334,7 +1309,8 @@ static int collect(ds_index *index, hipStream_t stream, int64_t stats[32])
         DS_HIP(hipMemcpy(phase, index->phase.ptr, sizeof(phase), hipMemcpyDeviceToHost));
         fprintf(stderr, "phase cycles:");
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %d=%llu", i, phase[i]);
-        fprintf(stderr, "\n");
+        fprintf(stderr, "\nrejectable with 8/16/32/128 signature bits: %d %d %d %d of %d raw entries\n", control[20], control[21],
+                control[22], control[23], control[kCtlRawEntries]);
     }
     if (stats) {
         stats[0] = control[kCtlSlowCount];
