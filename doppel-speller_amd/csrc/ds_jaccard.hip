@@ -88,7 +88,7 @@ constexpr int kFastLdsBytes = kOffCtrl + 128;
 static_assert((kFastLdsBytes + 256) * kWorkgroupsPerCu <= 160 * 1024, "LDS budget of one CU exceeded");
 static_assert(kCandidates * 16 <= 32768 && 32768 + kCandidates * 8 <= kTile * 2, "exact-stage scratch fits the tile");
 static_assert(kMaxQueryColumns == 128, "two ballots cover the query's columns");
-constexpr int kRefineBatch = 128;  // raw entries that make a refine pass worth its three barriers
+constexpr int kRefineBatch = 256;  // raw entries that make a refine pass worth its three barriers
 constexpr int kRefineRoom = 512;   // refine when fewer free candidate slots than this remain
 constexpr int kKeep = (kCandidates + kThreads - 1) / kThreads;  // candidate entries a thread holds while compacting
 constexpr int kSelectTrigger = kCandidates - kLooseStep;
@@ -285,6 +285,7 @@ __device__ __forceinline__ bool in_bounds(int32_t *control, int site, int64_t in
 
 // Diagnostic phase timers: thread 0 adds the shader-clock delta since its previous stamp to an LDS accumulator
 // (flushed to HBM once, at the end of the kernel, so that stamping does not put a global atomic in front of a barrier).
+#ifdef DS_DIAGNOSTICS
 #define DS_STAMP(slot)                                                     \
     do {                                                                   \
         if (a.phase != nullptr && tid == 0) {                              \
@@ -293,12 +294,24 @@ __device__ __forceinline__ bool in_bounds(int32_t *control, int site, int64_t in
             stamp_ = now_;                                                 \
         }                                                                  \
     } while (0)
+#define DS_COUNT(slot, value)                                              \
+    do {                                                                   \
+        if (a.phase != nullptr && tid == 0) atomicAdd(&a.control[slot], value); \
+    } while (0)
+#define DS_DEBUG_BIT(bit) ((a.debug & (bit)) != 0)
+#else
+#define DS_STAMP(slot) do { } while (0)
+#define DS_COUNT(slot, value) do { } while (0)
+#define DS_DEBUG_BIT(bit) false
+#endif
 
 __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void ds_jaccard_topk_kernel(JaccardArgs a)
 {
+#ifdef DS_DIAGNOSTICS
     unsigned long long stamp_ = a.phase != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
     __shared__ unsigned long long phase_lds[16];
     if (threadIdx.x < 16) phase_lds[threadIdx.x] = 0ull;
+#endif
     extern __shared__ __align__(16) unsigned char lds[];
     uint32_t *cand_key = reinterpret_cast<uint32_t *>(lds + kOffLo);
     int32_t *cand_row = reinterpret_cast<int32_t *>(lds + kOffRow);
@@ -420,10 +433,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             const int last_raw = uniform(min(static_cast<int>(ctrl[kLCount]), kCandidates));
             if (last_raw <= first_raw) return;
             DS_STAMP(10);
-            if (tid == 0 && a.phase != nullptr) {
-                atomicAdd(&a.control[kCtlRefines], 1);
-                atomicAdd(&a.control[kCtlRawEntries], last_raw - first_raw);
-            }
+            DS_COUNT(kCtlRefines, 1);
+            DS_COUNT(kCtlRawEntries, last_raw - first_raw);
             uint32_t keep_key[kKeep];
             int32_t keep_row[kKeep];
 #pragma unroll
@@ -437,21 +448,6 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     if (!DS_OK_INDEX(1, t, a.n_truth)) continue;
                     const float sums = a.sums32[t];
                     const uint4 signature = skipped.count > 0 ? a.signature[t] : make_uint4(0u, 0u, 0u, 0u);
-                    if (a.phase != nullptr && (a.debug & 32)) {
-                        // diagnostics: would knowing only the first G signature bits of the row have rejected it?
-                        const uint32_t words[4] = {signature.x, signature.y, signature.z, signature.w};
-                        float lacking = 0.f;
-                        int slot = 20;
-                        for (int g = 0; g < kSignatureBits; ++g) {
-                            if (((skipped.sig_mask[g >> 5] >> (g & 31)) & 1u) && !((words[g >> 5] >> (g & 31)) & 1u))
-                                lacking += bit_idf[g];
-                            if (g == 7 || g == 15 || g == 31 || g == 127) {
-                                if (!(raw + (bounds.mass - lacking) * 1.0001f >= bounds.coef * (sums + bounds.maxint32)))
-                                    atomicAdd(&a.control[slot], 1);
-                                ++slot;
-                            }
-                        }
-                    }
                     if (may_qualify(raw, sums, bounds)) {
                         const float full = complete_score(raw, signature, skipped, bit_idf);
                         uint32_t key = 0;
@@ -474,7 +470,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 }
             }
             __syncthreads();
-            if (tid == 0 && a.phase != nullptr) atomicAdd(&a.control[kCtlSurvivors], ctrl[kLCount] - first_raw);
+            DS_COUNT(kCtlSurvivors, ctrl[kLCount] - first_raw);
             first_raw = uniform(static_cast<int>(ctrl[kLCount]));
             __syncthreads();  // every thread holds the same count before anything is appended again
             DS_STAMP(8);
@@ -485,39 +481,23 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             return count - first_raw >= refine_batch || count > kCandidates - kRefineRoom;
         };
 
-        // List pointers of kPtrTiles tiles for every query column (+ the tiles' min sums32), loaded into registers
-        // one tile before they are needed so that their latency hides behind that tile's work.
-        constexpr int kPrefetch = (kMaxQueryColumns * (kPtrTiles + 1) + kThreads - 1) / kThreads;
-        uint32_t pre_ptr[kPrefetch];
-        float pre_min = 0.f;
-        auto prefetch = [&](int b0) {
-            const int width = min(kPtrTiles, a.n_tiles - b0) + 1;
-#pragma unroll
-            for (int r = 0; r < kPrefetch; ++r) {
-                const int e = tid + r * kThreads;
-                const int j = e / (kPtrTiles + 1), i = e % (kPtrTiles + 1);
-                const bool ok = e < n * (kPtrTiles + 1) && i < width &&
-                                DS_OK_INDEX(2, static_cast<int64_t>(cols[j < n ? j : 0]) * ptr_stride + b0 + i,
-                                            a.n_columns * ptr_stride);
-                pre_ptr[r] = ok ? a.col_ptr[static_cast<int64_t>(cols[j]) * ptr_stride + b0 + i] : 0u;
-            }
-            pre_min = (tid < kPtrTiles && b0 + tid < a.n_tiles) ? a.tile_sums_min[b0 + tid] : 0.f;
-        };
-        if (!slow) prefetch(0);
-
+        int sparse_retries = 0;
         for (int b = 0; b < a.n_tiles && !slow; ++b) {
             const int bt = b % kPtrTiles;
-            if (bt == 0) {  // list pointers + min sums of the next kPtrTiles tiles: fetched one tile ahead, published here
+            bool redo_tile = false;
+            if (bt == 0) {  // list pointers + min sums32 of the next kPtrTiles tiles: one coalesced burst
                 __syncthreads();
-#pragma unroll
-                for (int r = 0; r < kPrefetch; ++r) {
-                    const int e = tid + r * kThreads;
-                    if (e < n * (kPtrTiles + 1)) ptr_cache[e] = pre_ptr[r];
+                const int width = min(kPtrTiles, a.n_tiles - b) + 1;
+                for (int e = tid; e < n * (kPtrTiles + 1); e += kThreads) {
+                    const int j = e / (kPtrTiles + 1), i = e % (kPtrTiles + 1);
+                    ptr_cache[e] = (i < width && DS_OK_INDEX(2, static_cast<int64_t>(cols[j]) * ptr_stride + b + i,
+                                                            a.n_columns * ptr_stride))
+                                       ? a.col_ptr[static_cast<int64_t>(cols[j]) * ptr_stride + b + i]
+                                       : 0u;
                 }
-                if (tid < kPtrTiles) ctrl[kLTileMin + tid] = __float_as_int(pre_min);
+                if (tid < kPtrTiles && b + tid < a.n_tiles) ctrl[kLTileMin + tid] = __float_as_int(a.tile_sums_min[b + tid]);
                 __syncthreads();
             }
-            if (bt == kPtrTiles - 1 && b + 1 < a.n_tiles) prefetch(b + 1);
             // raw entries were scored under the current set of skipped columns: refine them before it changes
             if (non_essential != skipped.count && first_raw != uniform(static_cast<int>(ctrl[kLCount]))) refine();
             bounds.mass = pending_mass;  // what this tile's scores do NOT contain; fixed until the tile is done
@@ -626,7 +606,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             uint2 quad[kRound], quad_info[kRound];
             bool live[kRound] = {false, false, false, false};  // a wave without items still runs the collect sweep
             const int count_before = count_at_step;
-            for (int round = (sparse && (a.debug & 1)) ? n_items : 0; wave + round * kWaves < n_items; round += kRound) {
+            for (int round = (sparse && DS_DEBUG_BIT(1)) ? n_items : 0; wave + round * kWaves < n_items; round += kRound) {
                 uint32_t value[kRound];
 #pragma unroll
                 for (int u = 0; u < kRound; ++u) {
@@ -665,7 +645,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             taken[e] = (live[u] && local[e] < kTile) ? take_packed(iscores, local[e]) : 0u;
-                        if (a.debug & 2) continue;
+                        if (DS_DEBUG_BIT(2)) continue;
                         const float s4[4] = {static_cast<float>(taken[0]) * from_fixed, static_cast<float>(taken[1]) * from_fixed,
                                              static_cast<float>(taken[2]) * from_fixed, static_cast<float>(taken[3]) * from_fixed};
                         const float bound4[4] = {decode_sums8(info[0] >> 8), decode_sums8(info[1] >> 8),
@@ -678,7 +658,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 if (single_round) {
                     collect();
                 } else {
-                    for (int round = (a.debug & 1) ? n_items : 0; wave + round * kWaves < n_items; round += kRound) {
+                    for (int round = DS_DEBUG_BIT(1) ? n_items : 0; wave + round * kWaves < n_items; round += kRound) {
 #pragma unroll
                         for (int u = 0; u < kRound; ++u) {
                             const int at = wave + (round + u) * kWaves;
@@ -693,9 +673,24 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 }
                 __syncthreads();
                 DS_STAMP(7);
-                if (uniform(static_cast<int>(ctrl[kLOverflow]))) { slow = true; reason = 2; break; }
-                if (tid == 0 && a.phase != nullptr) atomicAdd(&a.control[kCtlRawSparse], ctrl[kLCount] - count_before);
-                if (refine_due()) refine();
+                if (uniform(static_cast<int>(ctrl[kLOverflow]))) {
+                    // The sweep ran to its end, so the tile is all zero again, but some of its rows did not fit the
+                    // buffer: refine what is buffered, tighten the threshold with it, drop this tile's entries and
+                    // process the tile once more.
+                    if (++sparse_retries > 3) { slow = true; reason = 2; break; }
+                    __syncthreads();
+                    if (tid == 0) {
+                        ctrl[kLCount] = kCandidates;
+                        ctrl[kLOverflow] = 0;
+                    }
+                    __syncthreads();
+                    refine();
+                    redo_tile = true;
+                } else {
+                    sparse_retries = 0;
+                    DS_COUNT(kCtlRawSparse, ctrl[kLCount] - count_before);
+                    if (refine_due()) refine();
+                }
             }
 
             // ---- (2d) dense scan (and re-zero) of the tile; in steps while no running value exists
@@ -703,12 +698,16 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             const int limit = rows_left >= kTile ? kTile : static_cast<int>((rows_left + 7) & ~int64_t(7));
             int r0 = sparse ? limit : 0;
             if (!sparse) ++dense_tiles;
-            bool select_now = sparse && uniform(first_raw == ctrl[kLCount] && ctrl[kLCount] >= next_select);
+            bool select_now = sparse && (redo_tile || uniform(first_raw == ctrl[kLCount] && ctrl[kLCount] >= next_select));
             int retries = 0;
             bool probed = false;
-            int32_t drop_lo = 0, drop_hi = 0;  // rows to drop at the next pruning (a step that is scanned again)
+            // rows to drop at the next pruning (rows that are scanned / collected again)
+            int32_t drop_lo = redo_tile ? static_cast<int32_t>(tile_base) : 0;
+            int32_t drop_hi = redo_tile ? static_cast<int32_t>(tile_base + kTile) : 0;
+            bool force_pending = redo_tile;
             while (r0 < limit || select_now) {
-                bool force_select = false;
+                bool force_select = force_pending;
+                force_pending = false;
                 if (r0 < limit && !tight && !probed && k <= kProbeMaxK && count_at_step == 0) {
                     // ---- threshold bootstrap.  No threshold yet and nothing buffered: instead of flooding the
                     // candidate buffer with every positive row, each thread picks the best of its 32 rows of this
@@ -758,7 +757,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     // A thread reads eight rows (one uint4 of packed scores) per iteration; the `sums32` loads of a
                     // batch of iterations are issued together, ahead of the LDS work, so a batch exposes one HBM latency.
                     constexpr int kBatch = DS_SCAN_BATCH;
-                    for (int base = ((a.debug & 8) && b > 0) ? r1 : r0 + tid * 8; base < r1; base += kBatch * kThreads * 8) {
+                    for (int base = (DS_DEBUG_BIT(8) && b > 0) ? r1 : r0 + tid * 8; base < r1; base += kBatch * kThreads * 8) {
                         float4 sums_lo[kBatch], sums_hi[kBatch];
 #pragma unroll
                         for (int it = 0; it < kBatch; ++it) {
@@ -785,7 +784,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                                 any = any || sv[e] + here.mass >= here.pre;
                             }
                             if (__ballot(any) == 0) continue;
-                            if ((a.debug & 4) && b > 0) continue;
+                            if (DS_DEBUG_BIT(4) && b > 0) continue;
                             const float mass4[4] = {here.mass, here.mass, here.mass, here.mass};
                             {
                                 const float s4[4] = {sv[0], sv[1], sv[2], sv[3]};
@@ -944,6 +943,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 count_at_step = kept;
                 DS_STAMP(4);
             }
+            if (redo_tile && !slow) --b;  // the for statement steps back onto the same tile
         }
 
         if (!slow) {
@@ -1083,8 +1083,10 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             DS_STAMP(0);
         }
     }
+#ifdef DS_DIAGNOSTICS
     if (a.phase != nullptr && tid == 0)
         for (int i = 0; i < 16; ++i) atomicAdd(&a.phase[i], phase_lds[i]);
+#endif
 }
 
 // ---- the literal algorithm for the queries the fast kernel hands over ------------------------------------------------
@@ -1276,7 +1278,7 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     args.n_queries = Q;
     args.n_tiles = static_cast<int32_t>(index->n_tiles);
     args.k = k;
-    args.sparse_quads = 1024;  // measured: 512..1024 is the flat optimum on C2 (profiles/r01_d_tuning.txt)
+    args.sparse_quads = 4096;  // measured on C2: 2048..8192 is the flat optimum for 28672-row tiles (profiles/r01_i_tuning.txt)
     if (const char *limit = getenv("DS_SPARSE_QUADS"); limit != nullptr) args.sparse_quads = atoi(limit);
     args.sums_min = index->sums_min;
     args.debug = 0;
@@ -1309,8 +1311,7 @@ static int collect(ds_index *index, hipStream_t stream, int64_t stats[32])
         DS_HIP(hipMemcpy(phase, index->phase.ptr, sizeof(phase), hipMemcpyDeviceToHost));
         fprintf(stderr, "phase cycles:");
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %d=%llu", i, phase[i]);
-        fprintf(stderr, "\nrejectable with 8/16/32/128 signature bits: %d %d %d %d of %d raw entries\n", control[20], control[21],
-                control[22], control[23], control[kCtlRawEntries]);
+        fprintf(stderr, "\n");
     }
     if (stats) {
         stats[0] = control[kCtlSlowCount];
