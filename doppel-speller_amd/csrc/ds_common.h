@@ -21,10 +21,10 @@ namespace ds {
 #define DS_TILE_ROWS 28672
 #endif
 #ifndef DS_CANDIDATES
-#define DS_CANDIDATES 1536
+#define DS_CANDIDATES 2048
 #endif
 #ifndef DS_PTR_TILES
-#define DS_PTR_TILES 4
+#define DS_PTR_TILES 3
 #endif
 constexpr int kTile = DS_TILE_ROWS;          // truth rows per tile (multiple of 4096): 56 KiB of packed 16-bit scores
 constexpr int kSentinel = kTile;             // padding entry of a posting quad: lands in the trash word after the tile

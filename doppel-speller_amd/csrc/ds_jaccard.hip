@@ -82,8 +82,9 @@ constexpr int kOffFixed = kOffBitIdf + kSignatureBits * 4;
 constexpr int kOffTotal = kOffFixed + kMaxQueryColumns * 4;
 constexpr int kOffMassTable = kOffTotal + kMaxQueryColumns * 4;
 constexpr int kOffPtr = kOffMassTable + 256 * 4;
-constexpr int kOffHist = kOffPtr + kMaxQueryColumns * (kPtrTiles + 1) * 4;
-constexpr int kOffCtrl = kOffHist + 256 * 4;
+constexpr int kOffHist = kOffMassTable;  // the radix histogram shares the mass table: every selection is followed by
+                                         // a rebuild of the table before its next use
+constexpr int kOffCtrl = kOffPtr + kMaxQueryColumns * (kPtrTiles + 1) * 4;
 constexpr int kFastLdsBytes = kOffCtrl + 128;
 static_assert((kFastLdsBytes + 256) * kWorkgroupsPerCu <= 160 * 1024, "LDS budget of one CU exceeded");
 static_assert(kCandidates * 16 <= 32768 && 32768 + kCandidates * 8 <= kTile * 2, "exact-stage scratch fits the tile");
@@ -93,6 +94,9 @@ constexpr int kRefineRoom = 512;   // refine when fewer free candidate slots tha
 constexpr int kKeep = (kCandidates + kThreads - 1) / kThreads;  // candidate entries a thread holds while compacting
 constexpr int kSelectTrigger = kCandidates - kLooseStep;
 constexpr int kWaves = kThreads / 64;
+#ifndef DS_ROUND
+#define DS_ROUND 4
+#endif
 #ifndef DS_SCAN_BATCH
 #define DS_SCAN_BATCH 1
 #endif
@@ -601,10 +605,12 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             // ---- (1) scatter: fixed-point LDS atomics; padding entries hit the trash word.  Wave w takes the items
             // w, w + kWaves, ...: four of them (one quad per lane each) are in flight at a time.  On a sparse tile whose
             // items fit one round the quads (and their per-posting info) stay in registers for the collect sweep.
-            constexpr int kRound = 4;
+            constexpr int kRound = DS_ROUND;
             const bool single_round = sparse && n_items <= kRound * kWaves;
             uint2 quad[kRound], quad_info[kRound];
-            bool live[kRound] = {false, false, false, false};  // a wave without items still runs the collect sweep
+            bool live[kRound];  // a wave without items still runs the collect sweep
+#pragma unroll
+            for (int u = 0; u < kRound; ++u) live[u] = false;
             const int count_before = count_at_step;
             for (int round = (sparse && DS_DEBUG_BIT(1)) ? n_items : 0; wave + round * kWaves < n_items; round += kRound) {
                 uint32_t value[kRound];
