@@ -130,13 +130,18 @@ __device__ __forceinline__ float round_up_positive(double x)
     return f;
 }
 
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t value, int lane)
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (no LDS crossbar round trips): Hillis-Steele
+// inside each row of 16 lanes, then lane 15 of a row into the next row, then lane 31 into the upper half.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t value, int)
 {
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t other = __shfl_up(value, d);
-        if (lane >= d) value += other;
-    }
-    return value;
+    int v = static_cast<int>(value);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return static_cast<uint32_t>(v);
 }
 
 // k-th largest key of keys[0..m) (m >= k) by an 8-bit radix select.  All threads of the workgroup call it.
