@@ -56,7 +56,6 @@ struct JaccardArgs {
     int32_t n_tiles;
     int32_t k;
     int32_t sparse_quads;       // tiles with at most this many essential quads are handled sparsely
-    int32_t refine_batch;       // raw entries that trigger a refine pass
     int32_t debug;              // timing experiments only (DS_DEBUG)
     int64_t n_quads;            // posting quads in the index (bounds of `postings`)
     float sums_min;
@@ -71,7 +70,8 @@ enum { kCtlQueue = 0, kCtlSlowCount = 1, kCtlErrors = 2, kCtlExact = 3, kCtlSele
 constexpr int kScoreWords = kTile / 2 + 16;  // two 16-bit scores per word + the trash word of the padding entries
 constexpr int kOffLo = kScoreWords * 4;
 constexpr int kOffRow = kOffLo + kCandidates * 4;
-constexpr int kOffCols = kOffRow + kCandidates * 4;
+constexpr int kOffRaw = kOffRow + kCandidates * 4;  // per wave: 64 raw (score, row) entries awaiting refinement
+constexpr int kOffCols = kOffRaw + (kThreads / 64) * 64 * 8;
 constexpr int kOffIdf = kOffCols + kMaxQueryColumns * 4;
 constexpr int kOffRank = kOffIdf + kMaxQueryColumns * 4;
 constexpr int kOffOrder = kOffRank + kMaxQueryColumns * 4;
@@ -89,8 +89,6 @@ constexpr int kFastLdsBytes = kOffCtrl + 128;
 static_assert((kFastLdsBytes + 256) * kWorkgroupsPerCu <= 160 * 1024, "LDS budget of one CU exceeded");
 static_assert(kCandidates * 16 <= 32768 && 32768 + kCandidates * 8 <= kTile * 2, "exact-stage scratch fits the tile");
 static_assert(kMaxQueryColumns == 128, "two ballots cover the query's columns");
-constexpr int kRefineBatch = 256;  // raw entries that make a refine pass worth its three barriers
-constexpr int kRefineRoom = 512;   // refine when fewer free candidate slots than this remain
 constexpr int kKeep = (kCandidates + kThreads - 1) / kThreads;  // candidate entries a thread holds while compacting
 constexpr int kSelectTrigger = kCandidates - kLooseStep;
 constexpr int kWaves = kThreads / 64;
@@ -425,8 +423,6 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
         Skipped skipped{0, {0u, 0u, 0u, 0u}};
         bool sparse_mode = false;  // decided at every selection from the essential columns' remaining length
         bool rebuild_mass_table = false;
-        int first_raw = 0;  // candidate entries [first_raw, count) are RAW: not yet refined
-        const int refine_batch = a.refine_batch;
         int non_essential = 0;
         bool tight = false;
         int next_select = max(4 * k, 64);
@@ -434,60 +430,43 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
         int selects = 0, sparse_tiles = 0, dense_tiles = 0, last_appended = 0;
         DS_STAMP(0);
 
-        // `refine` turns the RAW entries (approximate essential score, row) appended by the sweeps into candidates:
-        // exact sums, completion of the skipped columns from the signature, tight test -- one thread per entry --
-        // or drops them.  Deferred until enough raw entries exist; always runs before a selection, so every raw
-        // entry was produced under the current `skipped` set.  Called by all threads after a barrier; ends with one.
-        auto refine = [&]() {
-            const int last_raw = uniform(min(static_cast<int>(ctrl[kLCount]), kCandidates));
-            if (last_raw <= first_raw) return;
-            DS_STAMP(10);
+        // Rows passing the register-level tests of a sweep are RAW entries (approximate essential score, row).  A wave
+        // parks them in its private LDS buffer and refines them itself, 64 at a time and always before it leaves the
+        // tile: exact sums, completion of the skipped columns from the signature, tight test -- one lane per entry,
+        // no workgroup barrier; only the survivors reach the shared candidate buffer.  Every raw entry is therefore
+        // refined under the set of skipped columns it was scored with.
+        uint2 *wave_raw = reinterpret_cast<uint2 *>(lds + kOffRaw) + wave * 64;
+        int raw_count = 0;  // wave-uniform
+        auto flush_raw = [&]() {
+            if (raw_count == 0) return;
             DS_COUNT(kCtlRefines, 1);
-            DS_COUNT(kCtlRawEntries, last_raw - first_raw);
-            uint32_t keep_key[kKeep];
-            int32_t keep_row[kKeep];
-#pragma unroll
-            for (int r = 0; r < kKeep; ++r) {
-                const int i = first_raw + tid + r * kThreads;
-                keep_row[r] = -1;
-                keep_key[r] = 0u;
-                const int32_t t = i < last_raw ? cand_row[i] : -1;
-                if (t >= 0) {
-                    const float raw = __uint_as_float(cand_key[i]);
-                    if (!DS_OK_INDEX(1, t, a.n_truth)) continue;
+            const bool mine = lane < raw_count;
+            bool ok = false;
+            uint32_t key = 0;
+            int32_t t = -1;
+            if (mine) {
+                const uint2 entry = wave_raw[lane];
+                const float raw = __uint_as_float(entry.x);
+                t = static_cast<int32_t>(entry.y);
+                if (DS_OK_INDEX(1, t, a.n_truth)) {
                     const float sums = a.sums32[t];
                     const uint4 signature = skipped.count > 0 ? a.signature[t] : make_uint4(0u, 0u, 0u, 0u);
                     if (may_qualify(raw, sums, bounds)) {
                         const float full = complete_score(raw, signature, skipped, bit_idf);
-                        uint32_t key = 0;
-                        if (candidate_key(full, sums, bounds, key)) {
-                            keep_key[r] = key;
-                            keep_row[r] = t;
-                        }
+                        ok = candidate_key(full, sums, bounds, key);
                     }
                 }
             }
-            __syncthreads();
-            if (tid == 0) ctrl[kLCount] = first_raw;
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < kKeep; ++r) {
-                if (keep_row[r] >= 0) {
-                    const int slot = atomicAdd(const_cast<int32_t *>(&ctrl[kLCount]), 1);
-                    cand_key[slot] = keep_key[r];
-                    cand_row[slot] = keep_row[r];
-                }
-            }
-            __syncthreads();
-            DS_COUNT(kCtlSurvivors, ctrl[kLCount] - first_raw);
-            first_raw = uniform(static_cast<int>(ctrl[kLCount]));
-            __syncthreads();  // every thread holds the same count before anything is appended again
-            DS_STAMP(8);
+            raw_count = 0;
+            append_candidate(ok, key, t, cand_key, cand_row, ctrl, lane);
         };
-        // refine when raw entries pile up, when a selection is due, or when the buffer runs short of room
-        auto refine_due = [&]() {
-            const int count = uniform(static_cast<int>(ctrl[kLCount]));
-            return count - first_raw >= refine_batch || count > kCandidates - kRefineRoom;
+        auto append_raw = [&](bool pass, uint32_t score_bits, int32_t row) {
+            const unsigned long long votes = __ballot(pass);
+            if (votes == 0) return;
+            const int count = __popcll(votes);
+            if (raw_count + count > 64) flush_raw();
+            if (pass) wave_raw[raw_count + __popcll(votes & ((1ull << lane) - 1ull))] = make_uint2(score_bits, static_cast<uint32_t>(row));
+            raw_count += count;
         };
 
         int sparse_retries = 0;
@@ -507,8 +486,6 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 if (tid < kPtrTiles && b + tid < a.n_tiles) ctrl[kLTileMin + tid] = __float_as_int(a.tile_sums_min[b + tid]);
                 __syncthreads();
             }
-            // raw entries were scored under the current set of skipped columns: refine them before it changes
-            if (non_essential != skipped.count && first_raw != uniform(static_cast<int>(ctrl[kLCount]))) refine();
             bounds.mass = pending_mass;  // what this tile's scores do NOT contain; fixed until the tile is done
             skipped.count = non_essential;
             for (int w = 0; w < kSignatureWords; ++w) skipped.sig_mask[w] = pending_sig_mask[w];
@@ -589,7 +566,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 if (gate > here.pre) here.pre = gate;
             }
             // A sweep only runs the register-level tests and appends RAW entries (approximate essential score, row);
-            // `refine` later turns raw entries into candidates or drops them.
+            // the wave refines them (flush_raw) before it leaves the tile.
             auto passes = [&](float s, float sums_lower_bound, float row_mass) {
                 return s > 0.f && s + row_mass >= here.pre &&
                        s + row_mass >= here.coef * (sums_lower_bound + here.maxint32);
@@ -603,8 +580,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 if (__ballot(pass[0] || pass[1] || pass[2] || pass[3]) == 0) return;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    append_candidate(pass[e], __float_as_uint(s[e]), static_cast<int32_t>(tile_base + local[e]),
-                                     cand_key, cand_row, ctrl, lane);
+                    append_raw(pass[e], __float_as_uint(s[e]), static_cast<int32_t>(tile_base + local[e]));
             };
 
             // ---- (1) scatter: fixed-point LDS atomics; padding entries hit the trash word.  Wave w takes the items
@@ -631,7 +607,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 }
 #pragma unroll
                 for (int u = 0; u < kRound; ++u) {
-                    if (!live[u]) continue;
+                    if (!live[u] || (sparse && DS_DEBUG_BIT(64))) continue;
                     add_packed(iscores, quad[u].x & 0xffffu, value[u]);
                     add_packed(iscores, quad[u].x >> 16, value[u]);
                     add_packed(iscores, quad[u].y & 0xffffu, value[u]);
@@ -655,7 +631,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                         uint32_t taken[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            taken[e] = (live[u] && local[e] < kTile) ? take_packed(iscores, local[e]) : 0u;
+                            taken[e] = (live[u] && local[e] < kTile && !DS_DEBUG_BIT(16)) ? take_packed(iscores, local[e]) : 0u;
                         if (DS_DEBUG_BIT(2)) continue;
                         const float s4[4] = {static_cast<float>(taken[0]) * from_fixed, static_cast<float>(taken[1]) * from_fixed,
                                              static_cast<float>(taken[2]) * from_fixed, static_cast<float>(taken[3]) * from_fixed};
@@ -682,12 +658,13 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                         collect();
                     }
                 }
+                flush_raw();
                 __syncthreads();
                 DS_STAMP(7);
                 if (uniform(static_cast<int>(ctrl[kLOverflow]))) {
                     // The sweep ran to its end, so the tile is all zero again, but some of its rows did not fit the
-                    // buffer: refine what is buffered, tighten the threshold with it, drop this tile's entries and
-                    // process the tile once more.
+                    // buffer: tighten the threshold with what is buffered, drop this tile's entries and process the
+                    // tile once more.
                     if (++sparse_retries > 3) { slow = true; reason = 2; break; }
                     __syncthreads();
                     if (tid == 0) {
@@ -695,12 +672,10 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                         ctrl[kLOverflow] = 0;
                     }
                     __syncthreads();
-                    refine();
                     redo_tile = true;
                 } else {
                     sparse_retries = 0;
                     DS_COUNT(kCtlRawSparse, ctrl[kLCount] - count_before);
-                    if (refine_due()) refine();
                 }
             }
 
@@ -709,7 +684,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             const int limit = rows_left >= kTile ? kTile : static_cast<int>((rows_left + 7) & ~int64_t(7));
             int r0 = sparse ? limit : 0;
             if (!sparse) ++dense_tiles;
-            bool select_now = sparse && (redo_tile || uniform(first_raw == ctrl[kLCount] && ctrl[kLCount] >= next_select));
+            bool select_now = sparse && (redo_tile || uniform(static_cast<int>(ctrl[kLCount])) >= next_select);
             int retries = 0;
             bool probed = false;
             // rows to drop at the next pruning (rows that are scanned / collected again)
@@ -751,7 +726,6 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     cand_row[tid] = -1;
                     if (tid == 0) ctrl[kLCount] = kThreads;
                     __syncthreads();
-                    first_raw = kThreads;
                     force_select = true;
                     DS_STAMP(11);
                 } else if (r0 < limit) {
@@ -768,7 +742,11 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     // A thread reads eight rows (one uint4 of packed scores) per iteration; the `sums32` loads of a
                     // batch of iterations are issued together, ahead of the LDS work, so a batch exposes one HBM latency.
                     constexpr int kBatch = DS_SCAN_BATCH;
-                    for (int base = (DS_DEBUG_BIT(8) && b > 0) ? r1 : r0 + tid * 8; base < r1; base += kBatch * kThreads * 8) {
+                    // the trip count is workgroup-uniform (a wave keeps all its lanes through the loop: the raw-entry
+                    // buffer is addressed by lane); rows beyond the tile's end are masked by `valid`
+                    const int scan_steps = (DS_DEBUG_BIT(8) && b > 0) ? 0 : (r1 - r0 + kBatch * kThreads * 8 - 1) / (kBatch * kThreads * 8);
+                    for (int step = 0; step < scan_steps; ++step) {
+                        const int base = r0 + tid * 8 + step * kBatch * kThreads * 8;
                         float4 sums_lo[kBatch], sums_hi[kBatch];
 #pragma unroll
                         for (int it = 0; it < kBatch; ++it) {
@@ -782,9 +760,9 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
 #pragma unroll
                         for (int it = 0; it < kBatch; ++it) {
                             const int idx = base + it * kThreads * 8;
-                            if (idx >= r1) continue;
-                            const uint4 raw4 = *reinterpret_cast<uint4 *>(&iscores[idx >> 1]);
-                            if (!recoverable) *reinterpret_cast<uint4 *>(&iscores[idx >> 1]) = make_uint4(0u, 0u, 0u, 0u);
+                            const bool valid = idx < r1;
+                            const uint4 raw4 = valid ? *reinterpret_cast<uint4 *>(&iscores[idx >> 1]) : make_uint4(0u, 0u, 0u, 0u);
+                            if (valid && !recoverable) *reinterpret_cast<uint4 *>(&iscores[idx >> 1]) = make_uint4(0u, 0u, 0u, 0u);
                             const uint32_t words[4] = {raw4.x, raw4.y, raw4.z, raw4.w};
                             float sv[8];
                             bool any = false;
@@ -813,12 +791,13 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                             }
                         }
                     }
+                    flush_raw();
                     __syncthreads();
                     DS_STAMP(3);
                     last_appended = uniform(static_cast<int>(ctrl[kLCount])) - count_at_step;
                     if (uniform(static_cast<int>(ctrl[kLOverflow]))) {
-                        // the buffer holds as many of the step's rows as fitted: refine them, tighten the threshold
-                        // with them, drop the step's rows from the buffer and scan the same rows again
+                        // the buffer holds as many of the step's rows as fitted: tighten the threshold with them,
+                        // drop the step's rows from the buffer and scan the same rows again
                         if (!recoverable || ++retries > 4) { slow = true; reason = 3; break; }
                         __syncthreads();
                         if (tid == 0) {
@@ -826,7 +805,6 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                             ctrl[kLOverflow] = 0;
                         }
                         __syncthreads();
-                        refine();
                         force_select = true;
                         drop_lo = static_cast<int32_t>(tile_base + r0);
                         drop_hi = static_cast<int32_t>(tile_base + r1);
@@ -839,14 +817,12 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                         }
                         r0 = r1;
                         retries = 0;
-                        if (!tight || refine_due()) refine();
                     }
                     DS_STAMP(12);
                 }
                 select_now = false;
                 const int m = uniform(static_cast<int>(ctrl[kLCount]));
-                // raw entries are refined before any selection
-                if ((m < next_select && !force_select) || first_raw != m || m < k) {
+                if ((m < next_select && !force_select) || m < k) {
                     if (force_select) { slow = true; reason = 3; break; }  // nothing to tighten with
                     continue;
                 }
@@ -950,17 +926,13 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 __syncthreads();  // a retried scan appends right away: the count must be read by all threads first
                 if (kept > kSelectTrigger) { slow = true; reason = 4; break; }  // massive ties: use the dense kernel
                 next_select = min(kSelectTrigger, max(2 * kept, max(4 * k, 64)));
-                first_raw = kept;
                 count_at_step = kept;
                 DS_STAMP(4);
             }
             if (redo_tile && !slow) --b;  // the for statement steps back onto the same tile
         }
 
-        if (!slow) {
-            __syncthreads();
-            refine();
-        }
+        if (!slow) __syncthreads();
         int m = slow ? 0 : uniform(static_cast<int>(ctrl[kLCount]));
         if (!slow && m < k) { slow = true; reason = 5; }  // fewer than k positive rows: literal path decides
         if (!slow) {
@@ -1294,9 +1266,7 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     args.sums_min = index->sums_min;
     args.debug = 0;
     args.n_quads = index->n_quads;
-    args.refine_batch = kRefineBatch;
     if (const char *debug = getenv("DS_DEBUG"); debug != nullptr) args.debug = atoi(debug);
-    if (const char *batch = getenv("DS_REFINE_BATCH"); batch != nullptr) args.refine_batch = atoi(batch);
 
     const int grid = static_cast<int>(std::min<int64_t>(Q, int64_t(index->compute_units) * kWorkgroupsPerCu));
     DS_HIP(hipMemsetAsync(index->control.ptr, 0, kControlWords * sizeof(int32_t), stream));
