@@ -1074,7 +1074,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
 
 // ---- the literal algorithm for the queries the fast kernel hands over ------------------------------------------------
 constexpr int kDenseScoreFloats = kTile + 64;  // float32 score tile + trash slot
-constexpr int kDenseLdsBytes = kDenseScoreFloats * 4 + 256 * 4 + 64 + (kDenseThreads / 64) * 4;
+constexpr int kDenseChunk = 256;  // query columns whose (list begin, list end, idf) are staged in LDS at a time
+constexpr int kDenseLdsBytes = kDenseScoreFloats * 4 + 256 * 4 + 64 + (kDenseThreads / 64) * 4 + 64 + kDenseChunk * 12;
 
 __global__ __launch_bounds__(kDenseThreads) void ds_jaccard_dense_kernel(JaccardArgs a)
 {
@@ -1083,6 +1084,9 @@ __global__ __launch_bounds__(kDenseThreads) void ds_jaccard_dense_kernel(Jaccard
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + kDenseScoreFloats * 4);
     volatile int32_t *ctrl = reinterpret_cast<volatile int32_t *>(lds + kDenseScoreFloats * 4 + 1024);
     int32_t *wave_counts = const_cast<int32_t *>(ctrl) + 16;
+    uint32_t *stage_begin = reinterpret_cast<uint32_t *>(lds + kDenseScoreFloats * 4 + 1024 + 64 + (kDenseThreads / 64) * 4 + 64);
+    uint32_t *stage_end = stage_begin + kDenseChunk;
+    float *stage_value = reinterpret_cast<float *>(stage_end + kDenseChunk);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.k;
@@ -1116,25 +1120,75 @@ __global__ __launch_bounds__(kDenseThreads) void ds_jaccard_dense_kernel(Jaccard
             continue;
         }
 
-        // fast_jaccard, tile by tile: ordered float32 accumulation (a barrier between two columns), float64 finalise
+        // fast_jaccard, tile by tile: ordered float32 accumulation (a barrier between two columns), float64 finalise.
+        // The histogram of the first radix pass (top 8 bits of the float32 value) is taken while finalising.
+        if (tid < 256) hist[tid] = 0;
         for (int b = 0; b < a.n_tiles; ++b) {
             for (int i = tid; i < kDenseScoreFloats; i += kDenseThreads) scores[i] = 0.f;
             __syncthreads();
-            for (int64_t j = 0; j < n; ++j) {
-                const int32_t column = a.q_cols[qbase + j];
-                const float value = a.idf32[column];
-                const uint32_t *ptr = a.col_ptr + static_cast<int64_t>(column) * ptr_stride + b;
-                const uint32_t begin = ptr[0] * 4u, end = ptr[1] * 4u;
-                for (uint32_t i = begin + tid; i < end; i += kDenseThreads) {
-                    const uint32_t local = a.postings[i];
-                    if (local < kTile) scores[local] = scores[local] + value;  // each row at most once per list
+            for (int64_t j0 = 0; j0 < n; j0 += kDenseChunk) {
+                // stage (list begin, list end, idf) of up to kDenseChunk columns: one round of loads instead of a
+                // chain of three dependent loads in front of every column
+                const int width = static_cast<int>(n - j0 < kDenseChunk ? n - j0 : kDenseChunk);
+                if (tid < width) {
+                    const int32_t column = a.q_cols[qbase + j0 + tid];
+                    const uint32_t *ptr = a.col_ptr + static_cast<int64_t>(column) * ptr_stride + b;
+                    stage_begin[tid] = ptr[0] * 4u;
+                    stage_end[tid] = ptr[1] * 4u;
+                    stage_value[tid] = a.idf32[column];
                 }
                 __syncthreads();
+                // the first four strides of the next column's list are fetched before the barrier that ends the
+                // current column, so that only the ordered LDS updates sit between two barriers
+                uint32_t next[4];
+                auto fetch = [&](int j) {
+                    const uint32_t begin = stage_begin[j], end = stage_end[j];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t i = begin + tid + u * kDenseThreads;
+                        next[u] = i < end ? a.postings[i] : static_cast<uint32_t>(kSentinel);
+                    }
+                };
+                fetch(0);
+                for (int j = 0; j < width; ++j) {
+                    const float value = stage_value[j];
+                    const uint32_t begin = stage_begin[j], end = stage_end[j];
+                    uint32_t local[4] = {next[0], next[1], next[2], next[3]};
+                    if (j + 1 < width) fetch(j + 1);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (local[u] < kTile) scores[local[u]] = scores[local[u]] + value;  // each row at most once per list
+                    for (uint32_t i0 = begin + tid + 4 * kDenseThreads; i0 < end; i0 += 4 * kDenseThreads) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t i = i0 + u * kDenseThreads;
+                            local[u] = i < end ? a.postings[i] : static_cast<uint32_t>(kSentinel);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (local[u] < kTile) scores[local[u]] = scores[local[u]] + value;
+                    }
+                    __syncthreads();
+                }
             }
             const int64_t tile_base = static_cast<int64_t>(b) * kTile;
-            for (int i = tid; i < kTile && tile_base + i < n_truth; i += kDenseThreads) {
-                const double s = static_cast<double>(scores[i]);
-                jaccard[tile_base + i] = s / (static_cast<double>(a.sums32[tile_base + i]) + (maxint - s));
+            for (int i0 = tid; i0 < kTile && tile_base + i0 < n_truth; i0 += 4 * kDenseThreads) {
+                float sums[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * kDenseThreads;
+                    sums[u] = (i < kTile && tile_base + i < n_truth) ? a.sums32[tile_base + i] : 1.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * kDenseThreads;
+                    if (!(i < kTile && tile_base + i < n_truth)) continue;
+                    const double s = static_cast<double>(scores[i]);
+                    const double v = s / (static_cast<double>(sums[u]) + (maxint - s));  // match_maker.py:50
+                    jaccard[tile_base + i] = v;
+                    const uint32_t key = v > 0.0 ? __float_as_uint(static_cast<float>(v)) : 0u;
+                    if (key != 0u) atomicAdd(&hist[key >> 24], 1u);
+                }
             }
             __syncthreads();
         }
@@ -1145,14 +1199,25 @@ __global__ __launch_bounds__(kDenseThreads) void ds_jaccard_dense_kernel(Jaccard
         int remaining = k;
         bool fewer = false;
         for (int shift = 24; shift >= 0; shift -= 8) {
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            for (int64_t t = tid; t < n_truth; t += kDenseThreads) {
-                const double v = jaccard[t];
-                const uint32_t key = v > 0.0 ? __float_as_uint(static_cast<float>(v)) : 0u;
-                if (key != 0u && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            if (shift != 24) {
+                if (tid < 256) hist[tid] = 0;
+                __syncthreads();
+                // eight independent loads in flight per thread: the pass is bound by latency otherwise
+                for (int64_t t0 = tid; t0 < n_truth; t0 += 8 * kDenseThreads) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int64_t t = t0 + u * kDenseThreads;
+                        v[u] = t < n_truth ? jaccard[t] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const uint32_t key = v[u] > 0.0 ? __float_as_uint(static_cast<float>(v[u])) : 0u;
+                        if (key != 0u && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
             if (tid == 0) {
                 int cumulative = 0, digit = -1;
                 for (int d = 255; d >= 0; --d) {
@@ -1174,12 +1239,21 @@ __global__ __launch_bounds__(kDenseThreads) void ds_jaccard_dense_kernel(Jaccard
         const double threshold = static_cast<double>(kth32) - static_cast<double>(1e-6f);
 
         // (array >= threshold).nonzero()[0][::-1][:k]
+        // Rounds of 8 * kDenseThreads rows from the top; thread `tid` owns eight consecutive rows (all eight loads in
+        // flight), a block-wide prefix of the per-thread counts gives every qualifying row its descending position.
         int found = 0;
-        for (int64_t top = n_truth - 1; top >= 0 && found < k; top -= kDenseThreads) {
-            const int64_t t = top - tid;
-            const bool pass = t >= 0 && jaccard[t] >= threshold;
-            const unsigned long long votes = __ballot(pass);
-            if (lane == 0) wave_counts[wave] = __popcll(votes);
+        constexpr int kPer = 8;
+        for (int64_t top = n_truth - 1; top >= 0 && found < k; top -= kPer * kDenseThreads) {
+            const int64_t first = top - static_cast<int64_t>(tid) * kPer;  // this thread: rows first, first - 1, ...
+            double v[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) v[u] = first - u >= 0 ? jaccard[first - u] : -1.0;
+            uint32_t pass_bits = 0;
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) pass_bits |= (first - u >= 0 && v[u] >= threshold) ? 1u << u : 0u;
+            const int mine = __popc(pass_bits);
+            const int inclusive = static_cast<int>(wave_inclusive_scan(static_cast<uint32_t>(mine), lane));
+            if (lane == 63) wave_counts[wave] = inclusive;
             __syncthreads();
             int before = 0, total = 0;
             for (int w = 0; w < kDenseThreads / 64; ++w) {
@@ -1187,9 +1261,13 @@ __global__ __launch_bounds__(kDenseThreads) void ds_jaccard_dense_kernel(Jaccard
                 before += w < wave ? c : 0;
                 total += c;
             }
-            if (pass) {
-                const int slot = found + before + __popcll(votes & ((1ull << lane) - 1ull));
-                if (slot < k) a.out_rows[q * k + slot] = static_cast<int32_t>(t);
+            int slot = found + before + inclusive - mine;
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                if ((pass_bits >> u) & 1u) {
+                    if (slot < k) a.out_rows[q * k + slot] = static_cast<int32_t>(first - u);
+                    ++slot;
+                }
             }
             found += total;
             __syncthreads();
