@@ -70,8 +70,8 @@ enum { kCtlQueue = 0, kCtlSlowCount = 1, kCtlErrors = 2, kCtlExact = 3, kCtlSele
 constexpr int kScoreWords = kTile / 2 + 16;  // two 16-bit scores per word + the trash word of the padding entries
 constexpr int kOffLo = kScoreWords * 4;
 constexpr int kOffRow = kOffLo + kCandidates * 4;
-constexpr int kOffRaw = kOffRow + kCandidates * 4;  // per wave: 64 raw (score, row) entries awaiting refinement
-constexpr int kOffCols = kOffRaw + (kThreads / 64) * 64 * 8;
+constexpr int kOffRaw = kOffRow + kCandidates * 4;  // per wave: 64 raw entries (fixed-point score << 16 | tile-local row)
+constexpr int kOffCols = kOffRaw + (kThreads / 64) * 64 * 4;
 constexpr int kOffIdf = kOffCols + kMaxQueryColumns * 4;
 constexpr int kOffRank = kOffIdf + kMaxQueryColumns * 4;
 constexpr int kOffOrder = kOffRank + kMaxQueryColumns * 4;
@@ -435,7 +435,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
         // tile: exact sums, completion of the skipped columns from the signature, tight test -- one lane per entry,
         // no workgroup barrier; only the survivors reach the shared candidate buffer.  Every raw entry is therefore
         // refined under the set of skipped columns it was scored with.
-        uint2 *wave_raw = reinterpret_cast<uint2 *>(lds + kOffRaw) + wave * 64;
+        uint32_t *wave_raw = reinterpret_cast<uint32_t *>(lds + kOffRaw) + wave * 64;
+        int64_t raw_tile_base = 0;  // the tile the parked entries belong to (they never outlive it)
         int raw_count = 0;  // wave-uniform
         auto flush_raw = [&]() {
             if (raw_count == 0) return;
@@ -445,9 +446,9 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             uint32_t key = 0;
             int32_t t = -1;
             if (mine) {
-                const uint2 entry = wave_raw[lane];
-                const float raw = __uint_as_float(entry.x);
-                t = static_cast<int32_t>(entry.y);
+                const uint32_t entry = wave_raw[lane];
+                const float raw = static_cast<float>(entry >> 16) * from_fixed;
+                t = static_cast<int32_t>(raw_tile_base + (entry & 0xffffu));
                 if (DS_OK_INDEX(1, t, a.n_truth)) {
                     const float sums = a.sums32[t];
                     const uint4 signature = skipped.count > 0 ? a.signature[t] : make_uint4(0u, 0u, 0u, 0u);
@@ -460,12 +461,12 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             raw_count = 0;
             append_candidate(ok, key, t, cand_key, cand_row, ctrl, lane);
         };
-        auto append_raw = [&](bool pass, uint32_t score_bits, int32_t row) {
+        auto append_raw = [&](bool pass, uint32_t fixed_score, uint32_t local_row) {
             const unsigned long long votes = __ballot(pass);
             if (votes == 0) return;
             const int count = __popcll(votes);
             if (raw_count + count > 64) flush_raw();
-            if (pass) wave_raw[raw_count + __popcll(votes & ((1ull << lane) - 1ull))] = make_uint2(score_bits, static_cast<uint32_t>(row));
+            if (pass) wave_raw[raw_count + __popcll(votes & ((1ull << lane) - 1ull))] = (fixed_score << 16) | local_row;
             raw_count += count;
         };
 
@@ -572,16 +573,17 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                        s + row_mass >= here.coef * (sums_lower_bound + here.maxint32);
             };
             // four rows at a time: one ballot decides whether anything needs appending (the common case: nothing)
-            auto consider4 = [&](const float (&s)[4], const uint32_t (&local)[4], const float (&sums_lower_bound)[4],
-                                 const float (&row_mass)[4]) {
+            auto consider4 = [&](const uint32_t (&fixed_score)[4], const uint32_t (&local)[4],
+                                 const float (&sums_lower_bound)[4], const float (&row_mass)[4]) {
                 bool pass[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pass[e] = passes(s[e], sums_lower_bound[e], row_mass[e]);
+                for (int e = 0; e < 4; ++e)
+                    pass[e] = passes(static_cast<float>(fixed_score[e]) * from_fixed, sums_lower_bound[e], row_mass[e]);
                 if (__ballot(pass[0] || pass[1] || pass[2] || pass[3]) == 0) return;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    append_raw(pass[e], __float_as_uint(s[e]), static_cast<int32_t>(tile_base + local[e]));
+                for (int e = 0; e < 4; ++e) append_raw(pass[e], fixed_score[e], local[e]);
             };
+            raw_tile_base = tile_base;
 
             // ---- (1) scatter: fixed-point LDS atomics; padding entries hit the trash word.  Wave w takes the items
             // w, w + kWaves, ...: four of them (one quad per lane each) are in flight at a time.  On a sparse tile whose
@@ -633,13 +635,11 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                         for (int e = 0; e < 4; ++e)
                             taken[e] = (live[u] && local[e] < kTile && !DS_DEBUG_BIT(16)) ? take_packed(iscores, local[e]) : 0u;
                         if (DS_DEBUG_BIT(2)) continue;
-                        const float s4[4] = {static_cast<float>(taken[0]) * from_fixed, static_cast<float>(taken[1]) * from_fixed,
-                                             static_cast<float>(taken[2]) * from_fixed, static_cast<float>(taken[3]) * from_fixed};
                         const float bound4[4] = {decode_sums8(info[0] >> 8), decode_sums8(info[1] >> 8),
                                                  decode_sums8(info[2] >> 8), decode_sums8(info[3] >> 8)};
                         const float mass4[4] = {mass_table[info[0] & 0xffu], mass_table[info[1] & 0xffu],
                                                 mass_table[info[2] & 0xffu], mass_table[info[3] & 0xffu]};
-                        consider4(s4, local, bound4, mass4);
+                        consider4(taken, local, bound4, mass4);
                     }
                 };
                 if (single_round) {
@@ -764,26 +764,26 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                             const uint4 raw4 = valid ? *reinterpret_cast<uint4 *>(&iscores[idx >> 1]) : make_uint4(0u, 0u, 0u, 0u);
                             if (valid && !recoverable) *reinterpret_cast<uint4 *>(&iscores[idx >> 1]) = make_uint4(0u, 0u, 0u, 0u);
                             const uint32_t words[4] = {raw4.x, raw4.y, raw4.z, raw4.w};
-                            float sv[8];
+                            uint32_t fx[8];
                             bool any = false;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                sv[e] = static_cast<float>((words[e >> 1] >> ((e & 1) * 16)) & 0xffffu) * from_fixed;
+                                fx[e] = (words[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
                                 // mass < pre by construction, so untouched rows (score 0) never pass
-                                any = any || sv[e] + here.mass >= here.pre;
+                                any = any || static_cast<float>(fx[e]) * from_fixed + here.mass >= here.pre;
                             }
                             if (__ballot(any) == 0) continue;
                             if (DS_DEBUG_BIT(4) && b > 0) continue;
                             const float mass4[4] = {here.mass, here.mass, here.mass, here.mass};
                             {
-                                const float s4[4] = {sv[0], sv[1], sv[2], sv[3]};
+                                const uint32_t s4[4] = {fx[0], fx[1], fx[2], fx[3]};
                                 const uint32_t rows4[4] = {static_cast<uint32_t>(idx), static_cast<uint32_t>(idx + 1),
                                                            static_cast<uint32_t>(idx + 2), static_cast<uint32_t>(idx + 3)};
                                 const float bound4[4] = {sums_lo[it].x, sums_lo[it].y, sums_lo[it].z, sums_lo[it].w};
                                 consider4(s4, rows4, bound4, mass4);
                             }
                             {
-                                const float s4[4] = {sv[4], sv[5], sv[6], sv[7]};
+                                const uint32_t s4[4] = {fx[4], fx[5], fx[6], fx[7]};
                                 const uint32_t rows4[4] = {static_cast<uint32_t>(idx + 4), static_cast<uint32_t>(idx + 5),
                                                            static_cast<uint32_t>(idx + 6), static_cast<uint32_t>(idx + 7)};
                                 const float bound4[4] = {sums_hi[it].x, sums_hi[it].y, sums_hi[it].z, sums_hi[it].w};
