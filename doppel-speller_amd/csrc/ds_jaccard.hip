@@ -103,7 +103,7 @@ constexpr int kProbeMaxK = kThreads / 4;  // threshold bootstrap from per-thread
 
 // LDS control words
 enum { kLQuery = 0, kLCount, kLOverflow, kLDigit, kLRemain, kLCoef, kLPre, kLCut, kLKth0, kLKth1, kLBad, kLItems,
-       kLQuads, kLNonEssential, kLMass, kLSparse, kLSigMask /* 4 words */, kLEnd = kLSigMask + 4,
+       kLQuads, kLNonEssential, kLMass, kLSparse, kLSigMask /* 4 words */, kLQuant = kLSigMask + 4 /* quantisation error of the query's columns, 1/65536 units */, kLEnd,
        kLTileMin = 24 /* kPtrTiles floats: min sums32 of the cached tiles */ };
 static_assert(kLEnd <= kLTileMin && kLTileMin + kPtrTiles <= 32, "LDS control words");
 
@@ -354,6 +354,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             ctrl[kLCount] = 0;
             ctrl[kLOverflow] = 0;
             ctrl[kLBad] = 0;
+            ctrl[kLQuant] = 0;
         }
         __syncthreads();
         const int64_t q = uniform(static_cast<int>(ctrl[kLQuery]));
@@ -413,10 +414,26 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
         // the low half of a word never carries into the high half.
         const float total_mass = uniform(n > 0 ? fmaxf(maxint32, mass_upto[n - 1]) : maxint32);
         const float to_fixed = uniform(kFixedOne / total_mass), from_fixed = uniform(total_mass * (1.f / kFixedOne));
-        if (tid < n) fixed[tid] = max(1u, static_cast<uint32_t>(idf[tid] * to_fixed + 0.5f));
+        if (tid < kMaxQueryColumns) {
+            // fixed-point image of every column's IDF and the exact total of what the quantisation can be off by
+            uint32_t off = 0;
+            if (tid < n) {
+                const uint32_t f = max(1u, static_cast<uint32_t>(idf[tid] * to_fixed + 0.5f));
+                fixed[tid] = f;
+                const double unit = static_cast<double>(from_fixed);
+                off = static_cast<uint32_t>(fabs(static_cast<double>(idf[tid]) - f * unit) / unit * 65536.0) + 1u;
+            }
+            const uint32_t total_off = wave_inclusive_scan(off, lane);
+            if (lane == 63) atomicAdd(const_cast<int32_t *>(&ctrl[kLQuant]), static_cast<int32_t>(total_off));
+        }
         // |approximate jaccard - exact jaccard| <= margin (DESIGN.md "error margin of the prefilter"):
         // float32 evaluation + quantisation of n terms to one unit each (4 = bound of d jaccard / d score * total)
-        auto error_margin = [&]() { return (6.0 * n + 64.0) * 5.9604644775390625e-08 + n * (4.0 / kFixedOne) * 1.001; };
+        // float32 evaluation + the measured quantisation error of this query's columns (<= 1 unit each; typically
+        // a quarter of a unit), both relative to the total mass; 4 = bound of d jaccard / d score * total
+        auto error_margin = [&]() {
+            const double off_units = static_cast<double>(uniform(static_cast<int>(ctrl[kLQuant]))) * (1.0 / 65536.0);
+            return (6.0 * n + 64.0) * 5.9604644775390625e-08 + off_units * (4.0 / kFixedOne) * 1.001;
+        };
         Bounds bounds{0.f, FLT_MIN, 0.f, maxint32};
         float cut = 0.f, pending_mass = 0.f;  // mass of the columns skipped from the NEXT tile on
         uint32_t pending_sig_mask[kSignatureWords] = {0u, 0u, 0u, 0u};
