@@ -49,6 +49,8 @@ struct JaccardArgs {
     int32_t *control;
     int32_t *slow_list;
     double *slow_scratch;
+    uint32_t *slow_keys;        // [slots][slow_keys_cap] float32 keys of the rows that share the k-th value's top byte
+    int64_t slow_keys_cap;
     unsigned long long *phase;  // nullable: per-phase shader-clock sums (diagnostics, DS_PHASE_TIMERS=1)
     int64_t n_truth;
     int64_t n_columns;
@@ -1110,6 +1112,7 @@ __global__ __launch_bounds__(kDenseThreads) void ds_jaccard_dense_kernel(Jaccard
     const int64_t n_truth = a.n_truth;
     const int64_t ptr_stride = static_cast<int64_t>(a.n_tiles) + 1;
     double *jaccard = a.slow_scratch + static_cast<int64_t>(blockIdx.x) * n_truth;
+    uint32_t *compact = a.slow_keys + static_cast<int64_t>(blockIdx.x) * a.slow_keys_cap;
     const int n_slow = a.control[kCtlSlowCount];
 
     for (;;) {
@@ -1215,25 +1218,63 @@ __global__ __launch_bounds__(kDenseThreads) void ds_jaccard_dense_kernel(Jaccard
         uint32_t prefix = 0, mask = 0;
         int remaining = k;
         bool fewer = false;
+        // Pass 1 (top byte) was taken while finalising.  Pass 2 reads the whole row once more and, besides its own
+        // histogram, compacts the float32 keys that share the k-th value's top byte; passes 3 and 4 then read only
+        // that list (a fraction of N) -- unless it does not fit, in which case they scan the row again.
+        bool use_compact = false;
+        int compact_count = 0;
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (shift != 24) {
                 if (tid < 256) hist[tid] = 0;
+                if (tid == 0 && shift == 16) ctrl[kLCount] = 0;
                 __syncthreads();
-                // eight independent loads in flight per thread: the pass is bound by latency otherwise
-                for (int64_t t0 = tid; t0 < n_truth; t0 += 8 * kDenseThreads) {
-                    double v[8];
+                if (use_compact) {
+                    for (int i0 = tid; i0 < compact_count; i0 += 8 * kDenseThreads) {
+                        uint32_t key[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int64_t t = t0 + u * kDenseThreads;
-                        v[u] = t < n_truth ? jaccard[t] : 0.0;
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = i0 + u * kDenseThreads;
+                            key[u] = i < compact_count ? compact[i] : 0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (key[u] != 0u && (key[u] & mask) == prefix) atomicAdd(&hist[(key[u] >> shift) & 255u], 1u);
                     }
+                } else {
+                    // eight independent loads in flight per thread: the pass is bound by latency otherwise
+                    for (int64_t base = 0; base < n_truth; base += 8 * kDenseThreads) {  // uniform trip count
+                        const int64_t t0 = base + tid;
+                        double v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const uint32_t key = v[u] > 0.0 ? __float_as_uint(static_cast<float>(v[u])) : 0u;
-                        if (key != 0u && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+                        for (int u = 0; u < 8; ++u) {
+                            const int64_t t = t0 + u * kDenseThreads;
+                            v[u] = t < n_truth ? jaccard[t] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const uint32_t key = v[u] > 0.0 ? __float_as_uint(static_cast<float>(v[u])) : 0u;
+                            const bool match = key != 0u && (key & mask) == prefix;
+                            if (match) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+                            if (shift == 16) {  // wave-aggregated append to the compact list (all lanes take part)
+                                const unsigned long long votes = __ballot(match);
+                                if (votes != 0) {
+                                    const int leader = __ffsll(votes) - 1;
+                                    int base = 0;
+                                    if (lane == leader) base = atomicAdd(const_cast<int32_t *>(&ctrl[kLCount]), __popcll(votes));
+                                    base = __shfl(base, leader);
+                                    const int64_t slot = base + __popcll(votes & ((1ull << lane) - 1ull));
+                                    if (match && slot < a.slow_keys_cap) compact[slot] = key;
+                                }
+                            }
+                        }
                     }
                 }
                 __syncthreads();
+                if (shift == 16) {
+                    compact_count = ctrl[kLCount];
+                    use_compact = compact_count <= a.slow_keys_cap;
+                    __threadfence_block();
+                }
             }
             if (tid == 0) {
                 int cumulative = 0, digit = -1;
@@ -1345,6 +1386,8 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     args.control = index->control.ptr;
     args.slow_list = index->slow_list.ptr;
     args.slow_scratch = index->slow_scratch.ptr;
+    args.slow_keys = index->slow_keys.ptr;
+    args.slow_keys_cap = index->slow_keys_cap;
     args.phase = nullptr;
     if (const char *timers = getenv("DS_PHASE_TIMERS"); timers != nullptr && timers[0] == '1') {
         if (index->phase.count == 0 && index->phase.allocate(16) != DS_OK) return DS_E_HIP;
