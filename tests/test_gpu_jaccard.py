@@ -82,6 +82,40 @@ def test_random_against_oracle(oracle, n_truth, k):
     assert index.sync()["error_queries"] == 0
 
 
+@pytest.mark.parametrize("n_truth,k", [(60000, 200), (90000, 512)])
+def test_large_k_without_sample_threshold(oracle, n_truth, k):
+    """k above the sample-threshold limit (128): the first threshold comes from a buffer flood and its recovery."""
+    rng = np.random.RandomState(n_truth + k)
+    problem = _random_problem(rng, n_truth, 2000, 48, mean_cols=14)
+    index = _check(oracle, problem, k)
+    assert index.sync()["error_queries"] == 0
+
+
+def test_heavy_queries_many_columns(oracle):
+    """Queries with 65..128 columns exercise the upper half of the per-wave item map (lanes own columns j, j + 64)."""
+    rng = np.random.RandomState(4242)
+    problem = _random_problem(rng, 120000, 1500, 4, mean_cols=10)
+    n_columns = problem["rowptr"].shape[0] - 1
+    idf64 = problem["idf32"].astype(np.float64)
+    q_cols = []
+    for q in range(40):
+        width = rng.randint(65, 129)
+        c = np.sort(rng.choice(n_columns, width, replace=False)).astype(np.int64)
+        q_cols.append(c[problem["idf32"][c] != 0])
+    problem["q_rowptr"] = np.concatenate(([0], np.cumsum([len(c) for c in q_cols]))).astype(np.int64)
+    problem["q_cols"] = np.concatenate(q_cols).astype(np.int32)
+    maxint = []
+    for c in q_cols:
+        total = 0.0
+        for value in idf64[c]:
+            total = total + float(value)
+        maxint.append(total)
+    problem["q_maxint"] = np.array(maxint)
+    index = _check(oracle, problem, 25)
+    stats = index.sync()
+    assert stats["error_queries"] == 0 and stats["dense_queries"] < 40  # handled by the fast kernel
+
+
 def test_ties_and_duplicates(oracle):
     rng = np.random.RandomState(5)
     problem = _random_problem(rng, 50000, 2000, 40, duplicates=6000)  # 6000 identical truth rows: massive ties
