@@ -15,5 +15,5 @@ from ._lib import DoppelError, build_library, library_path  # noqa: F401
 from .feature_engineering import (  # noqa: F401
     FEATURES_COUNT, TitleTable, construct_features, construct_features_indexed, encode_title, encode_titles,
     get_truth_words_counts, levenshtein_ratio_batch, find_close_matches, ALLOWED_CHARACTERS, SPACE_CODE, SORT_KEY)
-from .match_maker import MatchMaker, TruthIndex  # noqa: F401
+from .match_maker import MatchMaker, NativeProblem, TruthIndex  # noqa: F401
 from .pipeline import CandidatePipeline  # noqa: F401

@@ -5,7 +5,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-_SOURCES = ("ds_runtime.hip", "ds_jaccard.hip", "ds_features.hip")
+_SOURCES = ("ds_runtime.hip", "ds_jaccard.hip", "ds_features.hip", "ds_build.hip")
 _lib = None
 
 
@@ -57,6 +57,9 @@ def _declare(handle):
         "ds_levenshtein_ratio_batch": [p, p, p, p, c.c_int64, c.c_int, c.c_int, p],
         "ds_close_matches": [p, p, p, c.c_int32, c.c_int64, c.c_uint8, p, c.c_int32, p, p],
         "ds_close_matches_device": [p, p, p, c.c_int64, c.c_int32, c.c_int64, c.c_uint8, p, c.c_int32, p, p, p],
+        "ds_problem_create": [p, p, c.c_int64, p, p, c.c_int64, c.c_int32, c.POINTER(p)],
+        "ds_problem_info": [p, c.POINTER(c.c_int64)],
+        "ds_problem_arrays": [p] + [c.POINTER(p)] * 9,
         "ds_malloc": [c.POINTER(p), c.c_size_t, c.c_int],
         "ds_free": [p, c.c_int],
         "ds_memcpy_h2d": [p, p, c.c_size_t, c.c_int],
@@ -72,7 +75,7 @@ def _declare(handle):
         function = getattr(handle, name)
         function.argtypes = argtypes
         function.restype = c.c_int
-    for name in ("ds_index_destroy", "ds_titles_destroy", "ds_timer_destroy"):
+    for name in ("ds_index_destroy", "ds_titles_destroy", "ds_timer_destroy", "ds_problem_destroy"):
         function = getattr(handle, name)
         function.argtypes = [p]
         function.restype = None
@@ -83,7 +86,8 @@ EXPORTED_SYMBOLS = (
     "ds_last_error", "ds_version", "ds_device_count", "ds_device_name", "ds_index_create", "ds_index_destroy",
     "ds_index_info", "ds_jaccard_topk", "ds_jaccard_topk_device", "ds_jaccard_sync", "ds_construct_features",
     "ds_titles_create", "ds_titles_destroy", "ds_construct_features_indexed", "ds_construct_features_indexed_device",
-    "ds_levenshtein_ratio_batch", "ds_close_matches", "ds_close_matches_device", "ds_malloc", "ds_free", "ds_memcpy_h2d", "ds_memcpy_d2h", "ds_memset",
+    "ds_levenshtein_ratio_batch", "ds_close_matches", "ds_close_matches_device", "ds_problem_create",
+    "ds_problem_destroy", "ds_problem_info", "ds_problem_arrays", "ds_malloc", "ds_free", "ds_memcpy_h2d", "ds_memcpy_d2h", "ds_memset",
     "ds_stream_sync", "ds_timer_create", "ds_timer_destroy", "ds_timer_start", "ds_timer_stop",
     "ds_timer_elapsed_ms")
 

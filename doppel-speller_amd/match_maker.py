@@ -115,6 +115,67 @@ class TruthIndex:
             pass
 
 
+def _ptr(array):
+    return array.ctypes.data_as(ctypes.c_void_p)
+
+
+class NativeProblem:
+    """ctypes wrapper of `ds_problem_create` (include/doppel_amd.h, next row f-3): the host arrays of the index build
+    computed natively from the transformed titles.  Host code: works without a GPU."""
+
+    def __init__(self, truth_titles, query_titles, n_gram=3):
+        def pack(titles):
+            encoded = [t if isinstance(t, bytes) else str(t).encode("ascii") for t in titles]
+            offsets = np.zeros(len(encoded) + 1, dtype=np.int64)
+            np.cumsum([len(e) for e in encoded], out=offsets[1:])
+            chars = np.frombuffer(b"".join(encoded), dtype=np.uint8) if offsets[-1] else np.zeros(1, dtype=np.uint8)
+            return np.ascontiguousarray(chars), offsets
+        t_chars, t_offsets = pack(truth_titles)
+        q_chars, q_offsets = pack(query_titles)
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.lib().ds_problem_create(_ptr(t_chars), _ptr(t_offsets), len(truth_titles), _ptr(q_chars),
+                                                _ptr(q_offsets), len(query_titles), n_gram,
+                                                ctypes.byref(self.handle)), "ds_problem_create")
+        info = (ctypes.c_int64 * 8)()
+        _lib.check(_lib.lib().ds_problem_info(self.handle, info), "ds_problem_info")
+        self.n_truth, self.n_queries, self.n_columns, self.nnz, self.q_nnz, self.n_gram = list(info)[:6]
+
+    def arrays(self):
+        """Copies of the arrays (vocabulary keys, idf32, idf64, rowptr, truth_idx, sums32, q_rowptr, q_cols, q_maxint)."""
+        pointers = [ctypes.c_void_p() for _ in range(9)]
+        _lib.check(_lib.lib().ds_problem_arrays(self.handle, *[ctypes.byref(p) for p in pointers]), "ds_problem_arrays")
+        spec = (("vocabulary_keys", np.uint32, self.n_columns), ("idf32", np.float32, self.n_columns),
+                ("idf64", np.float64, self.n_columns), ("rowptr", np.int64, self.n_columns + 1),
+                ("truth_idx", np.int32, self.nnz), ("sums32", np.float32, self.n_truth),
+                ("q_rowptr", np.int64, self.n_queries + 1), ("q_cols", np.int32, self.q_nnz),
+                ("q_maxint", np.float64, self.n_queries))
+        out = {}
+        for (name, dtype, count), pointer in zip(spec, pointers):
+            if count == 0 or not pointer.value:
+                out[name] = np.zeros(0, dtype=dtype)
+                continue
+            buffer = (ctypes.c_char * (count * np.dtype(dtype).itemsize)).from_address(pointer.value)
+            out[name] = np.frombuffer(buffer, dtype=dtype, count=count).copy()
+        return out
+
+    def vocabulary(self):
+        """The n-gram string of every column, in column order."""
+        keys = self.arrays()["vocabulary_keys"]
+        n = self.n_gram
+        return [bytes((int(key) >> (8 * (n - 1 - i))) & 0xff for i in range(n)).decode("latin-1") for key in keys]
+
+    def close(self):
+        if self.handle:
+            _lib.lib().ds_problem_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class MatchMaker:
     """
     The class responsible for getting the closest (based on Jaccard distance) titles, given a collection of titles.
@@ -136,6 +197,16 @@ class MatchMaker:
 
         LOGGER.info(f'[{self.__class__.__name__}] Loading pre-requisite data!')
 
+        self._host_arrays(vocabulary)
+        rowptr, truth_idx, idf32 = self._truth_rowptr, self._truth_idx, self._idf32
+        self.truth_data = self.truth_data.loc[:, [COLUMN_TITLE_ID]]                         # :104
+        self.index = TruthIndex(rowptr, truth_idx, idf32, self.sums_matrix_truth, device)
+        self._rows = None
+
+        LOGGER.info(f'[{self.__class__.__name__}] Loaded pre-requisite data!')
+
+    def _host_arrays(self, vocabulary=None):
+        """Everything `__init__` derives on the host (match_maker.py:91-107), without touching the GPU."""
         self.n_grams_counter = self._count(self.data[COLUMN_N_GRAMS])               # match_maker.py:91
         self.n_grams_counter_truth = self._count(self.truth_data[COLUMN_N_GRAMS])   # :92
         self.number_of_truth_titles = len(self.truth_data)                           # :93
@@ -150,17 +221,47 @@ class MatchMaker:
         # idf per column, float64 (_get_idf_given_index, :180-181) and its float32 image (the matrix dtype, :152)
         self._idf64 = np.array([self.idf_s_mapping.get(self.n_grams_decoding[g], self.max_idf_value)
                                 for g in range(n_columns)], dtype=np.float64)
-        idf32 = self._idf64.astype(ENCODING_FLOAT_TYPE)
+        self._idf32 = self._idf64.astype(ENCODING_FLOAT_TYPE)
 
-        self._q_rowptr, self._q_cols, self._q_maxint = self._construct_data_rows(idf32)   # :99, :106, :197
-        del self.data                                                                       # :100
+        self._q_rowptr, self._q_cols, self._q_maxint = self._construct_data_rows(self._idf32)   # :99, :106, :197
+        del self.data                                                                             # :100
 
-        rowptr, truth_idx, self.sums_matrix_truth = self._construct_truth_index(idf32, n_columns)  # :102-107
-        self.truth_data = self.truth_data.loc[:, [COLUMN_TITLE_ID]]                         # :104
-        self.index = TruthIndex(rowptr, truth_idx, idf32, self.sums_matrix_truth, device)
+        self._truth_rowptr, self._truth_idx, self.sums_matrix_truth = \
+            self._construct_truth_index(self._idf32, n_columns)                                   # :102-107
+
+    @classmethod
+    def host_arrays(cls, data, truth_data, vocabulary=None):
+        """The host-side arrays of `MatchMaker(data, truth_data, ...)` as a dict, without a GPU (parity tests of the
+        native index build compare against this)."""
+        self = cls.__new__(cls)
+        self.data, self.truth_data = data, truth_data
+        self._host_arrays(vocabulary)
+        return dict(vocabulary=[self.n_grams_decoding[g] for g in range(len(self.n_grams_decoding))],
+                    idf32=self._idf32, idf64=self._idf64, rowptr=self._truth_rowptr, truth_idx=self._truth_idx,
+                    sums32=self.sums_matrix_truth, q_rowptr=self._q_rowptr, q_cols=self._q_cols,
+                    q_maxint=self._q_maxint)
+
+    @classmethod
+    def from_titles(cls, titles, truth_titles, top_n, title_ids=None, n_gram=3, device=0):
+        """Next row f-3: the same object built by the native index build (`ds_problem_create`) straight from the
+        transformed titles (`transform_title` output: ASCII byte strings) -- no per-title Python sets, no DataFrames.
+        `title_ids` (default: the truth row numbers) plays the role of `truth_data[title_id]`."""
+        import pandas as pd
+        problem = NativeProblem(truth_titles, titles, n_gram)
+        self = cls.__new__(cls)
+        self.top_n = top_n
+        self.number_of_truth_titles = problem.n_truth
+        arrays = problem.arrays()
+        self.n_grams_decoding = dict(enumerate(problem.vocabulary()))
+        self.n_grams_encoding = {v: k for k, v in self.n_grams_decoding.items()}
+        self._idf64, self._idf32 = arrays["idf64"], arrays["idf32"]
+        self._q_rowptr, self._q_cols, self._q_maxint = arrays["q_rowptr"], arrays["q_cols"], arrays["q_maxint"]
+        self.sums_matrix_truth = arrays["sums32"]
+        ids = np.arange(problem.n_truth) if title_ids is None else np.asarray(title_ids)
+        self.truth_data = pd.DataFrame({COLUMN_TITLE_ID: ids})
+        self.index = TruthIndex(arrays["rowptr"], arrays["truth_idx"], arrays["idf32"], arrays["sums32"], device)
         self._rows = None
-
-        LOGGER.info(f'[{self.__class__.__name__}] Loaded pre-requisite data!')
+        return self
 
     @staticmethod
     def _count(column):  # common.py:145-147 get_n_grams_counter

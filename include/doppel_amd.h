@@ -40,6 +40,7 @@ extern "C" {
 typedef struct ds_index ds_index;   /* truth inverted index resident in HBM (MatchMaker.__init__ product) */
 typedef struct ds_titles ds_titles; /* table of encoded titles resident in HBM */
 typedef struct ds_timer ds_timer;   /* pair of HIP events */
+typedef struct ds_problem ds_problem; /* host-side product of the native index build (next row f-3) */
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */
 const char *ds_last_error(void);
@@ -121,6 +122,23 @@ int ds_close_matches(ds_titles *queries, ds_titles *truth, const int32_t *pair_t
 int ds_close_matches_device(ds_titles *queries, ds_titles *truth, const int32_t *d_pair_t, int64_t q_first, int32_t k,
                             int64_t n_queries, uint8_t space_code, const uint8_t *d_sort_key, int32_t threshold,
                             uint8_t *d_ratios, int32_t *d_best_row, void *stream);
+
+/* ---- next row f-3: native index build ----------------------------------------------------------------------------
+ * Replaces the Python / lil_matrix loops of MatchMaker.__init__ (doppelspeller/match_maker.py:84-181) and
+ * get_n_grams / get_n_grams_counter (doppelspeller/common.py:145-151): from the transformed titles (byte strings,
+ * concatenated, offsets[n + 1]) to the arrays ds_index_create and ds_jaccard_topk take.  Host code.  Column ids
+ * ascend with the n-gram's byte string and a title's float32 idf sum runs in first-occurrence order of its n-grams
+ * (the reference leaves both to Python's set iteration order).  The arrays belong to the handle. */
+int ds_problem_create(const uint8_t *truth_chars, const int64_t *truth_offsets, int64_t n_truth,
+                      const uint8_t *query_chars, const int64_t *query_offsets, int64_t n_queries, int32_t n_gram,
+                      ds_problem **out);
+void ds_problem_destroy(ds_problem *problem);
+/* info: n_truth, n_queries, n_columns, nnz (truth), nnz (queries), n_gram */
+int ds_problem_info(const ds_problem *problem, int64_t info[8]);
+/* vocabulary[V]: the n-gram of every column as big-endian bytes in a uint32; any out pointer may be NULL */
+int ds_problem_arrays(const ds_problem *problem, const uint32_t **vocabulary, const float **idf32, const double **idf64,
+                      const int64_t **rowptr, const int32_t **truth_idx, const float **sums32, const int64_t **q_rowptr,
+                      const int32_t **q_cols, const double **q_maxint);
 
 /* ---- device memory / stream / timing plumbing (so tests and bench.py can keep inputs resident in HBM) ----------- */
 int ds_malloc(void **ptr, size_t bytes, int device);

@@ -194,3 +194,29 @@ def test_match_maker_drop_in(golden_match_maker):
         assert isinstance(ids, list) and len(ids) == 10
         agree += ids == g["ids_k10"][q].tolist()
     assert agree >= 198  # identical unless a set-order rounding difference in sums flips a near-tie
+
+
+def test_match_maker_from_titles_equals_dataframe_build():
+    """Next row f-3: MatchMaker.from_titles (native index build) answers like MatchMaker(data, truth) built from
+    DataFrames with the same column order and the same per-title summation order."""
+    import pandas as pd
+    import doppel_speller_amd as ds
+    from doppel_speller_amd import synth
+    w = synth.make_workload(60000, 300, seed=9)
+    truth, queries = synth._to_strings(w.t_flat, w.t_off), synth._to_strings(w.q_flat, w.q_off)
+
+    def ordered(title):
+        seen, out = set(), []
+        for i in range(len(title) - 2):
+            if title[i:i + 3] not in seen:
+                seen.add(title[i:i + 3])
+                out.append(title[i:i + 3])
+        return out
+    native = ds.MatchMaker.from_titles(queries, truth, 10, title_ids=w.title_id)
+    data = pd.DataFrame({"n_grams": [ordered(t) for t in queries], "title_id": np.arange(len(queries))})
+    frame = pd.DataFrame({"n_grams": [ordered(t) for t in truth], "title_id": w.title_id})
+    vocabulary = [native.n_grams_decoding[g] for g in range(len(native.n_grams_decoding))]
+    reference_style = ds.MatchMaker(data, frame, 10, vocabulary=vocabulary)
+    assert np.array_equal(native.get_closest_matches_batch(), reference_style.get_closest_matches_batch())
+    for row in (0, 17, 299):
+        assert native.get_closest_matches(row) == reference_style.get_closest_matches(row)
