@@ -260,12 +260,17 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(
                 w.recon[lr + match_length] = space;
                 w.features[6 + word] = static_cast<float>(best_ratio);                        // :151
                 w.features[6 + DS_WORDS + word] = static_cast<float>(length);                 // :152
-                w.features[6 + 2 * DS_WORDS + word] = static_cast<float>(
-                    log(static_cast<double>(a.n_truth) / static_cast<double>(a.t_counts[ti * DS_WORDS + word])));  // :153
             }
             lr += match_length + 1;
             wave_sync();
         }
+
+        // :153  idf_s of every word at once, one lane per word (the float64 log is ~150 instructions: evaluated once
+        // per pair for all lanes instead of once per word on a single lane)
+        if (lane < n_words)
+            w.features[6 + 2 * DS_WORDS + lane] = static_cast<float>(
+                log(static_cast<double>(a.n_truth) / static_cast<double>(a.t_counts[ti * DS_WORDS + lane])));
+        wave_sync();
 
         // :161-162  strip the first and the last space
         const uint8_t recon_ratio = levenshtein_wave(w, w.recon + 1, lr - 2, w.t, lt, lane, small_alphabet);
