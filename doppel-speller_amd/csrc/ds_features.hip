@@ -144,9 +144,17 @@ __device__ uint8_t levenshtein_wave(WaveScratch &w, const uint8_t *a, int la, co
     return levenshtein_literal(w, a, la, b, lb, lane);
 }
 
+// ratio_from_lcs for every (total length <= 128, LCS <= 64): what the word loop needs (window <= word <= 64 chars)
+constexpr int kRatioLengths = 129, kRatioLcs = 65;
+
 __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(FeatureArgs a)
 {
     __shared__ WaveScratch scratch[kFeatWaves];
+    // the float64 evaluation of :63 costs ~35 instructions per window; a workgroup tabulates it once
+    __shared__ uint8_t ratio_table[kRatioLengths * kRatioLcs];
+    for (int i = threadIdx.x; i < kRatioLengths * kRatioLcs; i += kFeatWaves * 64)
+        ratio_table[i] = ratio_from_lcs(i % kRatioLcs, i / kRatioLcs);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     WaveScratch &w = scratch[threadIdx.x >> 6];
     const int64_t wave_global = static_cast<int64_t>(blockIdx.x) * kFeatWaves + (threadIdx.x >> 6);
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(
                         if (start < lw) {
                             const int window = min(length, lw - start);                      // :142
                             const int lcs = lcs_bitparallel(w, w.qw + start, window, length);
-                            ratio = ratio_from_lcs(lcs, window + length);                    // :146
+                            ratio = ratio_table[(window + length) * kRatioLcs + lcs];         // :146
                         }
                     } else {
                         for (int s = base; s < min(base + 64, lw); ++s) {                    // literal, one window at a time
