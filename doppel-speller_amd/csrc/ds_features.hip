@@ -144,31 +144,112 @@ __device__ uint8_t levenshtein_wave(WaveScratch &w, const uint8_t *a, int la, co
     return levenshtein_literal(w, a, la, b, lb, lane);
 }
 
+// ---- construct_features: half a wavefront (32 lanes) per pair --------------------------------------------------------
+// The kernel is bound by vector-instruction issue, and most of a pair's work is either uniform over its lanes (the two
+// whole-title comparisons) or uses ~20 of them (one window start per lane).  Two pairs share a wavefront: every
+// instruction now serves two pairs.  Lanes 0-31 work on one pair, lanes 32-63 on another, each with its own scratch;
+// control flow may diverge between the halves (different word counts and lengths), never inside one.
+constexpr int kGroup = 32;
+
+// the ballot bits of this lane's half
+__device__ __forceinline__ uint32_t group_ballot(bool predicate, int group)
+{
+    return static_cast<uint32_t>(__ballot(predicate) >> (group * kGroup));
+}
+
+__device__ __forceinline__ void build_masks_g(WaveScratch &w, const uint8_t *pattern, int m, int gl)
+{
+    w.masks[gl] = 0ull;
+    w.masks[gl + kGroup] = 0ull;
+    wave_sync();
+    for (int j = gl; j < m; j += kGroup) atomicOr(&w.masks[pattern[j]], 1ull << j);
+    wave_sync();
+}
+
+// levenshtein_literal with 32 cooperating lanes
+__device__ uint8_t levenshtein_literal_g(WaveScratch &w, const uint8_t *a, int la, const uint8_t *b, int lb, int gl)
+{
+    const int total_length = la + lb;
+    if (la > lb) {  // :35-37
+        const uint8_t *ts = a; a = b; b = ts;
+        const int tl = la; la = lb; lb = tl;
+    }
+    for (int d = 0; d <= la + lb; ++d) {
+        uint8_t *current = w.diag[d % 3];
+        const uint8_t *previous = w.diag[(d + 2) % 3];
+        const uint8_t *before = w.diag[(d + 1) % 3];
+        const int x_low = d > lb ? d - lb : 0;
+        const int x_high = d < la ? d : la;
+        for (int x = x_low + gl; x <= x_high; x += kGroup) {
+            const int y = d - x;
+            int value;
+            if (x == 0) value = y;            // :45-46
+            else if (y == 0) value = x;       // :43-44
+            else {
+                const int up = previous[x - 1] + 1;
+                const int diagonal = before[x - 1] + (a[x - 1] == b[y - 1] ? 0 : 2);
+                const int left = previous[x] + 1;
+                value = min(up, min(diagonal, left));
+            }
+            current[x] = static_cast<uint8_t>(value);
+        }
+        wave_sync();
+    }
+    if (total_length == 0) return 0;
+    const int distance = w.diag[(la + lb) % 3][la];
+    const double ratio = (static_cast<double>(total_length - distance) / static_cast<double>(total_length)) * 100.0;
+    return static_cast<uint8_t>(ratio);
+}
+
+__device__ __forceinline__ bool codes_below_64_g(const uint8_t *s, int n, int gl, int group)
+{
+    bool ok = true;
+    for (int i = gl; i < n; i += kGroup) ok &= s[i] < 64;
+    return group_ballot(!ok, group) == 0u;
+}
+
+__device__ uint8_t levenshtein_g(WaveScratch &w, const uint8_t *a, int la, const uint8_t *b, int lb, int gl,
+                                 bool small_alphabet)
+{
+    const int shorter = la < lb ? la : lb;
+    if (small_alphabet && la + lb <= 255 && shorter <= 64) {
+        const uint8_t *pattern = la <= lb ? a : b;
+        const uint8_t *text = la <= lb ? b : a;
+        build_masks_g(w, pattern, shorter, gl);
+        const int lcs = lcs_bitparallel(w, text, la + lb - shorter, shorter);
+        return ratio_from_lcs(lcs, la + lb);
+    }
+    return levenshtein_literal_g(w, a, la, b, lb, gl);
+}
+
 // ratio_from_lcs for every (total length <= 128, LCS <= 64): what the word loop needs (window <= word <= 64 chars)
 constexpr int kRatioLengths = 129, kRatioLcs = 65;
 
 __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(FeatureArgs a)
 {
-    __shared__ WaveScratch scratch[kFeatWaves];
+    __shared__ WaveScratch scratch[kFeatWaves * 2];
     // the float64 evaluation of :63 costs ~35 instructions per window; a workgroup tabulates it once
     __shared__ uint8_t ratio_table[kRatioLengths * kRatioLcs];
     for (int i = threadIdx.x; i < kRatioLengths * kRatioLcs; i += kFeatWaves * 64)
         ratio_table[i] = ratio_from_lcs(i % kRatioLcs, i / kRatioLcs);
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    WaveScratch &w = scratch[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63, group = lane >> 5, gl = lane & (kGroup - 1);
+    WaveScratch &w = scratch[(threadIdx.x >> 6) * 2 + group];
     const int64_t wave_global = static_cast<int64_t>(blockIdx.x) * kFeatWaves + (threadIdx.x >> 6);
     const int64_t wave_count = static_cast<int64_t>(gridDim.x) * kFeatWaves;
     const uint8_t space = a.space_code;
     const float nan = __uint_as_float(0x7fc00000u);
 
-    for (int64_t pair = wave_global; pair < a.n; pair += wave_count) {
+    for (int64_t first_pair = wave_global * 2; first_pair < a.n; first_pair += wave_count * 2) {
+        const int64_t pair = first_pair + group;
+        if (pair >= a.n) continue;  // the odd last pair: the upper half idles (no wave-wide collective below needs it)
         float *out = a.out + pair * DS_FEATURES_COUNT;
         const int64_t qi = a.pair_q ? a.pair_q[pair] : (a.k > 0 ? a.q_first + pair / a.k : pair);
         const int64_t ti = a.pair_t ? a.pair_t[pair] : pair;
         if (qi < 0 || qi >= a.n_q || ti < 0 || ti >= a.n_t) {  // e.g. a -1 row of a failed top-k
-            out[lane] = nan;
-            if (lane < 2) out[64 + lane] = nan;
+            out[gl] = nan;
+            out[kGroup + gl] = nan;
+            if (gl < 2) out[64 + gl] = nan;
             continue;
         }
         const int lq = a.q_len[qi], lt = a.t_len[ti];                                      // :101-102
@@ -177,55 +258,58 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(
         wave_sync();
         // stage both strings; count spaces; squeeze the spaces out of the title (:104-108)
         int spaces_q = 0, spaces_t = 0, lw = 0;
-        for (int base = 0; base < 256; base += 64) {
-            const int i = base + lane;
+        const int longest = lq > lt ? lq : lt;
+        for (int base = 0; base < longest; base += kGroup) {
+            const int i = base + gl;
             const uint8_t cq = i < lq ? gq[i] : 0;
             const uint8_t ct = i < lt ? gt[i] : 0;
-            w.q[i] = cq;
-            w.t[i] = ct;
+            if (i < 256) {
+                w.q[i] = cq;
+                w.t[i] = ct;
+            }
             const bool is_char = i < lq && cq != space;
-            const unsigned long long keep = __ballot(is_char);
-            if (is_char) w.qw[lw + __popcll(keep & ((1ull << lane) - 1ull))] = cq;
-            lw += __popcll(keep);
-            spaces_q += __popcll(__ballot(i < lq && cq == space));
-            spaces_t += __popcll(__ballot(i < lt && ct == space));
+            const uint32_t keep = group_ballot(is_char, group);
+            if (is_char) w.qw[lw + __popc(keep & ((1u << gl) - 1u))] = cq;
+            lw += __popc(keep);
+            spaces_q += __popc(group_ballot(i < lq && cq == space, group));
+            spaces_t += __popc(group_ballot(i < lt && ct == space, group));
         }
         wave_sync();
         const int title_words = spaces_q + 1, truth_words = spaces_t + 1;
-        const bool small_alphabet = codes_below_64(w.q, lq, lane) && codes_below_64(w.t, lt, lane);
+        const bool small_alphabet = codes_below_64_g(w.q, lq, gl, group) && codes_below_64_g(w.t, lt, gl, group);
 
         // truth word boundaries: positions of the spaces of truth + [space], first 15 (:110-114)
         int n_words = 0;
         {
             int previous_end = 0;  // start of the current word
-            for (int base = 0; base <= lt && n_words < DS_WORDS; base += 64) {
-                const int i = base + lane;
+            for (int base = 0; base <= lt && n_words < DS_WORDS; base += kGroup) {
+                const int i = base + gl;
                 const bool is_space = i <= lt && (i == lt || w.t[i] == space);
-                unsigned long long votes = __ballot(is_space);
+                uint32_t votes = group_ballot(is_space, group);
                 while (votes && n_words < DS_WORDS) {
-                    const int position = base + __ffsll(votes) - 1;
-                    if (lane == 0) {
+                    const int position = base + __ffs(votes) - 1;
+                    if (gl == 0) {
                         w.word_begin[n_words] = previous_end;
                         w.word_len[n_words] = position - previous_end;
                     }
                     previous_end = position + 1;
                     ++n_words;
-                    votes &= votes - 1ull;
+                    votes &= votes - 1u;
                 }
             }
         }
         wave_sync();
 
-        const uint8_t lev_ratio = levenshtein_wave(w, w.q, lq, w.t, lt, lane, small_alphabet);  // :106
+        const uint8_t lev_ratio = levenshtein_g(w, w.q, lq, w.t, lt, gl, small_alphabet);  // :106
 
         // ---- truth words loop (:128-155)
-        if (lane < DS_WORDS) {
-            w.features[6 + lane] = nan;
-            w.features[6 + DS_WORDS + lane] = nan;
-            w.features[6 + 2 * DS_WORDS + lane] = nan;
+        if (gl < DS_WORDS) {
+            w.features[6 + gl] = nan;
+            w.features[6 + DS_WORDS + gl] = nan;
+            w.features[6 + 2 * DS_WORDS + gl] = nan;
         }
         int lr = 0;
-        if (lane == 0) w.recon[0] = space;  // :115
+        if (gl == 0) w.recon[0] = space;  // :115
         lr = 1;
         for (int word = 0; word < n_words; ++word) {
             const int begin = w.word_begin[word], length = w.word_len[word];
@@ -233,9 +317,9 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(
             int best_key = 0;  // (ratio << 8) | (255 - start): larger ratio first, then the earliest window
             if (length > 0 && lw > 0) {
                 const bool fast = small_alphabet && length <= 64;
-                if (fast) build_masks(w, truth_word, length, lane);
-                for (int base = 0; base < lw; base += 64) {
-                    const int start = base + lane;
+                if (fast) build_masks_g(w, truth_word, length, gl);
+                for (int base = 0; base < lw; base += kGroup) {
+                    const int start = base + gl;
                     int ratio = 0;
                     if (fast) {
                         if (start < lw) {
@@ -244,14 +328,14 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(
                             ratio = ratio_table[(window + length) * kRatioLcs + lcs];         // :146
                         }
                     } else {
-                        for (int s = base; s < min(base + 64, lw); ++s) {                    // literal, one window at a time
-                            const int window = min(length, lw - s);
-                            const uint8_t r = levenshtein_literal(w, w.qw + s, window, truth_word, length, lane);
-                            if (s == start) ratio = r;
+                        for (int s0 = base; s0 < min(base + kGroup, lw); ++s0) {              // literal, one window at a time
+                            const int window = min(length, lw - s0);
+                            const uint8_t r = levenshtein_literal_g(w, w.qw + s0, window, truth_word, length, gl);
+                            if (s0 == start) ratio = r;
                         }
                     }
                     int key = start < lw ? ((ratio << 8) | (255 - start)) : 0;
-                    for (int offset = 32; offset > 0; offset >>= 1) key = max(key, __shfl_xor(key, offset));
+                    for (int offset = kGroup / 2; offset > 0; offset >>= 1) key = max(key, __shfl_xor(key, offset, kGroup));
                     best_key = max(best_key, key);
                 }
             }
@@ -263,8 +347,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(
                 match_length = min(length, lw - match_start);
             }
             // reconstructed += best_match + [space]  (:154-155); best_match = [space] when nothing matched (:140)
-            for (int i = lane; i < match_length; i += 64) w.recon[lr + i] = matched ? w.qw[match_start + i] : space;
-            if (lane == 0) {
+            for (int i = gl; i < match_length; i += kGroup) w.recon[lr + i] = matched ? w.qw[match_start + i] : space;
+            if (gl == 0) {
                 w.recon[lr + match_length] = space;
                 w.features[6 + word] = static_cast<float>(best_ratio);                        // :151
                 w.features[6 + DS_WORDS + word] = static_cast<float>(length);                 // :152
@@ -275,22 +359,22 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(
 
         // :153  idf_s of every word at once, one lane per word (the float64 log is ~150 instructions: evaluated once
         // per pair for all lanes instead of once per word on a single lane)
-        if (lane < n_words)
-            w.features[6 + 2 * DS_WORDS + lane] = static_cast<float>(
-                log(static_cast<double>(a.n_truth) / static_cast<double>(a.t_counts[ti * DS_WORDS + lane])));
+        if (gl < n_words)
+            w.features[6 + 2 * DS_WORDS + gl] = static_cast<float>(
+                log(static_cast<double>(a.n_truth) / static_cast<double>(a.t_counts[ti * DS_WORDS + gl])));
         wave_sync();
 
         // :161-162  strip the first and the last space
-        const uint8_t recon_ratio = levenshtein_wave(w, w.recon + 1, lr - 2, w.t, lt, lane, small_alphabet);
+        const uint8_t recon_ratio = levenshtein_g(w, w.recon + 1, lr - 2, w.t, lt, gl, small_alphabet);
 
         // :158  ranks = 1 + (nanmax(idf_s) - idf_s) / truth_number_of_words   (float32 difference, float64 quotient)
-        float idf = lane < DS_WORDS ? w.features[6 + 2 * DS_WORDS + lane] : nan;
+        float idf = gl < DS_WORDS ? w.features[6 + 2 * DS_WORDS + gl] : nan;
         float maximum = idf;
         for (int offset = 8; offset > 0; offset >>= 1) {
             const float other = __shfl_xor(maximum, offset, 16);
             maximum = (other != other) ? maximum : ((maximum != maximum || other > maximum) ? other : maximum);
         }
-        if (lane < DS_WORDS) {
+        if (gl < DS_WORDS) {
             // NaN bit patterns follow x86-64 SSE (the reference's platform): a NaN operand propagates unchanged
             // (+qNaN from the np.nan fill of :121-123), an invalid operation (inf - inf when a word count is 0)
             // produces the default NaN, which has the sign bit set.
@@ -303,9 +387,9 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(
                            ? __uint_as_float(0xffc00000u)
                            : static_cast<float>(1.0 + static_cast<double>(difference) / static_cast<double>(truth_words));
             }
-            w.features[6 + 3 * DS_WORDS + lane] = rank;
+            w.features[6 + 3 * DS_WORDS + gl] = rank;
         }
-        if (lane == 0) {  // :164-167
+        if (gl == 0) {  // :164-167
             w.features[0] = static_cast<float>(lq);
             w.features[1] = static_cast<float>(lt);
             w.features[2] = static_cast<float>(title_words);
@@ -314,8 +398,9 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(
             w.features[5] = static_cast<float>(recon_ratio);
         }
         wave_sync();
-        out[lane] = w.features[lane];
-        if (lane < 2) out[64 + lane] = w.features[64 + lane];
+        out[gl] = w.features[gl];
+        out[kGroup + gl] = w.features[kGroup + gl];
+        if (gl < 2) out[64 + gl] = w.features[64 + gl];
     }
 }
 
@@ -523,7 +608,7 @@ static int launch_features(const FeatureArgs &args, int device, hipStream_t stre
 {
     if (args.n == 0) return DS_OK;
     (void)device;
-    const int64_t blocks_needed = (args.n + kFeatWaves - 1) / kFeatWaves;
+    const int64_t blocks_needed = (args.n + 2 * kFeatWaves - 1) / (2 * kFeatWaves);
     const int grid = static_cast<int>(std::min<int64_t>(blocks_needed, 256 * 32));
     hipLaunchKernelGGL(ds_construct_features_kernel, dim3(grid), dim3(kFeatWaves * 64), 0, stream, args);
     DS_HIP(hipGetLastError());
