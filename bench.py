@@ -220,16 +220,18 @@ def main():
             "queries_per_s": args.queries * world / (elapsed / args.steps),
             "dense_path_queries": int(stats["dense_queries"]), "exact_candidates_per_query":
                 stats["exact_candidates"] / max(1, args.queries),
-            "verified_queries": checked, "bounds_record": stats.get("bounds_record"), "selections_per_query": stats["selections"] / max(1, args.queries),
-            "phase_cycles": stats["phase_cycles"], "dense_reasons": stats["dense_reasons"],
+            "verified_queries": checked, "selections_per_query": stats["selections"] / max(1, args.queries),
+            "dense_reasons": stats["dense_reasons"],
             "tiles": {"sparse": stats["sparse_tiles"], "dense": stats["dense_tiles"]},
             "skipped_columns_per_query": stats["skipped_columns"] / max(1, args.queries),
-            "refine": {"calls": stats["refines"], "raw_entries": stats["raw_entries"],
-                       "survivors": stats["refine_survivors"], "raw_entries_sparse": stats["raw_entries_sparse"]},
             "roofline": {"bound": "hbm", "kernel": "ds_jaccard_topk_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_jaccard, "avg_launch_ms": mean_topk},
         }
+        if any(stats["phase_cycles"].values()):  # library built with -DDS_DIAGNOSTICS and DS_PHASE_TIMERS=1
+            line["diagnostics"] = {"phase_cycles": stats["phase_cycles"], "wave_refines": stats["refines"],
+                                   "raw_entries_sparse": stats["raw_entries_sparse"],
+                                   "bounds_record": stats.get("bounds_record")}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(workload, args.k, args.cpu_seconds)
         print(json.dumps(line), flush=True)
