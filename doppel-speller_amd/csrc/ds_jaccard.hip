@@ -642,6 +642,14 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 // ---- (2s) collect sweep over the same postings: the first lane to reach a row takes its score and
                 // leaves zero behind (no scan of the whole tile)
                 ++sparse_tiles;
+                // Cheap integer pre-test on the taken fixed-point scores: a row can only pass `s + mass >= pre` if its
+                // score reaches (pre - mass) in fixed-point units (rounded down, minus slack: a superset of the float
+                // test).  Most quads have no such row and skip the per-row decoding and table lookups altogether.
+                const uint32_t cheap_fixed = [&]() {
+                    const double units = (static_cast<double>(here.pre) - static_cast<double>(here.mass)) /
+                                         static_cast<double>(from_fixed) * (1.0 - 1e-6) - 2.0;
+                    return units > 1.0 ? static_cast<uint32_t>(units) : 1u;
+                }();
                 auto collect = [&]() {
 #pragma unroll
                     for (int u = 0; u < kRound; ++u) {
@@ -654,6 +662,9 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                         for (int e = 0; e < 4; ++e)
                             taken[e] = (live[u] && local[e] < kTile && !DS_DEBUG_BIT(16)) ? take_packed(iscores, local[e]) : 0u;
                         if (DS_DEBUG_BIT(2)) continue;
+                        if (__ballot(taken[0] >= cheap_fixed || taken[1] >= cheap_fixed || taken[2] >= cheap_fixed ||
+                                     taken[3] >= cheap_fixed) == 0)
+                            continue;
                         const float bound4[4] = {decode_sums8(info[0] >> 8), decode_sums8(info[1] >> 8),
                                                  decode_sums8(info[2] >> 8), decode_sums8(info[3] >> 8)};
                         const float mass4[4] = {mass_table[info[0] & 0xffu], mass_table[info[1] & 0xffu],
