@@ -34,10 +34,8 @@ constexpr int kDenseThreads = 1024;          // literal kernel: one 16-wave work
 static_assert(kTile % 4096 == 0 && kTile < 65536, "tile rows: whole scan iterations, 16-bit local indexes");
 constexpr int kMaxQueryColumns = 128;        // fast-path limit (example data: p99 50, max 96 tri-grams per title)
 constexpr int kCandidates = DS_CANDIDATES;            // capacity of the per-query candidate buffer in LDS
-constexpr int kLooseStep = 256;              // rows scanned between two capacity checks while no threshold exists
+constexpr int kSelectSlack = 256;            // a selection that keeps more than kCandidates - kSelectSlack hands the query over
 constexpr int kPtrTiles = DS_PTR_TILES;                 // tiles whose list pointers are cached in LDS at a time
-constexpr int kItemQuads = 256;              // a work item = up to 256 posting quads of one (tile, column) list
-constexpr int kMaxItems = 512;               // work items per (query, tile); more => dense kernel
 constexpr int kSignatureBits = 128;          // densest columns whose membership is kept as a per-row bit (uint4)
 constexpr int kSignatureWords = kSignatureBits / 32;
 constexpr int kControlWords = 32;            // int32 control block in HBM (queue heads, counters)

@@ -92,7 +92,7 @@ static_assert((kFastLdsBytes + 256) * kWorkgroupsPerCu <= 160 * 1024, "LDS budge
 static_assert(kCandidates * 16 <= 32768 && 32768 + kCandidates * 8 <= kTile * 2, "exact-stage scratch fits the tile");
 static_assert(kMaxQueryColumns == 128, "two ballots cover the query's columns");
 constexpr int kKeep = (kCandidates + kThreads - 1) / kThreads;  // candidate entries a thread holds while compacting
-constexpr int kSelectTrigger = kCandidates - kLooseStep;
+constexpr int kSelectTrigger = kCandidates - kSelectSlack;
 constexpr int kWaves = kThreads / 64;
 #ifndef DS_ROUND
 #define DS_ROUND 4
