@@ -168,6 +168,7 @@ def main():
 
     # ---- spot check against the oracle (outside the timed region)
     checked = 0
+    cells_per_pair = None
     if args.check > 0:
         from oracle import oracle
         n_check = min(args.check, args.queries)
@@ -184,6 +185,9 @@ def main():
                                               workload.t_enc[pair_t], workload.t_counts[pair_t], 1, workload.n_truth)
         assert np.array_equal(features.view(np.uint32), reference.view(np.uint32)), "features differ from the oracle"
         checked = n_check
+        # reference DP cells per pair (SURVEY 8d `cells(q,t)`) on the verified pairs: the unit of the features stage
+        cells_per_pair = float(np.mean(oracle.feature_cells(workload.q_len[pair_q], workload.t_len[pair_t],
+                                                            workload.q_enc[pair_q], workload.t_enc[pair_t], 1)))
 
     if rank == 0:
         pairs_per_step = args.queries * args.k * world
@@ -218,6 +222,14 @@ def main():
                           "ds_jaccard_topk_kernel": mean_topk,
                           "ds_jaccard_dense_kernel": float(np.mean(dense_kernel_ms))},
             "queries_per_s": args.queries * world / (elapsed / args.steps),
+            "per_stage": {
+                "jaccard_queries_per_s": args.queries / (mean_j * 1e-3),
+                "jaccard_postings_per_s": (bytes_jaccard - args.queries * (4 * args.truth + 4 * args.k)
+                                           - 16 * int(workload.q_rowptr[-1])) / 4 / (mean_j * 1e-3),
+                "feature_pairs_per_s": args.queries * args.k / (float(np.mean(feature_ms)) * 1e-3),
+                "feature_reference_dp_cells_per_s": None if cells_per_pair is None else
+                    cells_per_pair * args.queries * args.k / (float(np.mean(feature_ms)) * 1e-3),
+                "reference_dp_cells_per_pair": cells_per_pair},
             "dense_path_queries": int(stats["dense_queries"]), "exact_candidates_per_query":
                 stats["exact_candidates"] / max(1, args.queries),
             "verified_queries": checked, "selections_per_query": stats["selections"] / max(1, args.queries),
