@@ -58,6 +58,8 @@ struct JaccardArgs {
     int32_t n_tiles;
     int32_t k;
     int32_t sparse_quads;       // tiles with at most this many essential quads are handled sparsely
+    int32_t select_min;         // candidates that trigger the first selections
+    int32_t select_growth;      // next selection at select_growth / 2 times the kept candidates
     int32_t debug;              // timing experiments only (DS_DEBUG)
     int64_t n_quads;            // posting quads in the index (bounds of `postings`)
     float sums_min;
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
         bool rebuild_mass_table = false;
         int non_essential = 0;
         bool tight = false;
-        int next_select = max(4 * k, 64);
+        int next_select = max(4 * k, a.select_min);
         if (next_select > kSelectTrigger) next_select = kSelectTrigger;
         int selects = 0, sparse_tiles = 0, dense_tiles = 0, last_appended = 0;
         DS_STAMP(0);
@@ -955,7 +957,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 const int kept = uniform(static_cast<int>(ctrl[kLCount]));
                 __syncthreads();  // a retried scan appends right away: the count must be read by all threads first
                 if (kept > kSelectTrigger) { slow = true; reason = 4; break; }  // massive ties: use the dense kernel
-                next_select = min(kSelectTrigger, max(2 * kept, max(4 * k, 64)));
+                next_select = min(kSelectTrigger, max(a.select_growth * kept / 2, max(4 * k, a.select_min)));
                 count_at_step = kept;
                 DS_STAMP(4);
             }
@@ -1414,6 +1416,10 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     if (const char *limit = getenv("DS_SPARSE_QUADS"); limit != nullptr) args.sparse_quads = atoi(limit);
     args.sums_min = index->sums_min;
     args.debug = 0;
+    args.select_min = 64;
+    args.select_growth = 4;
+    if (const char *v = getenv("DS_SELECT_MIN"); v != nullptr) args.select_min = atoi(v);
+    if (const char *v = getenv("DS_SELECT_GROWTH"); v != nullptr) args.select_growth = atoi(v);
     args.n_quads = index->n_quads;
     if (const char *debug = getenv("DS_DEBUG"); debug != nullptr) args.debug = atoi(debug);
 
