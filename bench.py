@@ -238,7 +238,10 @@ def main():
             "skipped_columns_per_query": stats["skipped_columns"] / max(1, args.queries),
             "roofline": {"bound": "hbm", "kernel": "ds_jaccard_topk_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_jaccard, "avg_launch_ms": mean_topk},
+                         "algorithmic_bytes_per_launch": bytes_jaccard, "avg_launch_ms": mean_topk,
+                         "note": "algorithmic bytes = what the reference's algorithm reads (SURVEY 8d); the kernel "
+                                 "prunes most of it (MaxScore skipping, 2-byte postings), so achieved can exceed the "
+                                 "HBM peak; `traffic` is the measured FETCH_SIZE + WRITE_SIZE per launch"},
         }
         if any(stats["phase_cycles"].values()):  # library built with -DDS_DIAGNOSTICS and DS_PHASE_TIMERS=1
             line["diagnostics"] = {"phase_cycles": stats["phase_cycles"], "wave_refines": stats["refines"],
