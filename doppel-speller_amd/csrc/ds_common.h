@@ -124,6 +124,8 @@ struct ds_index {
     ds::DeviceBuffer<double> slow_scratch; // [kSlowSlots][n_truth] float64 jaccard rows of the exact dense kernel
     ds::DeviceBuffer<uint32_t> slow_keys;  // [kSlowSlots][slow_keys_cap] compacted float32 keys (radix passes 3 and 4)
     int64_t slow_keys_cap = 0;
+    bool literal_only = false;             // idf32 / sums32 hold negative or non-finite values: the bounds of the fast kernel
+                                           // do not apply, every query takes the literal kernel
     ds::DeviceBuffer<int32_t> control;     // [16] work-queue head, slow-list length, error count, counters
     ds::DeviceBuffer<int32_t> status;      // per-query status of the last call (grown on demand)
     ds::DeviceBuffer<int32_t> slow_list;   // query ids routed to the exact dense kernel

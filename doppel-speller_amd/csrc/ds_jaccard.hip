@@ -58,6 +58,7 @@ struct JaccardArgs {
     int32_t n_tiles;
     int32_t k;
     int32_t sparse_quads;       // tiles with at most this many essential quads are handled sparsely
+    int32_t literal_only;       // index holds values outside the fast kernel's assumptions: hand every query over
     int32_t select_min;         // candidates that trigger the first selections
     int32_t select_growth;      // next selection at select_growth / 2 times the kept candidates
     int32_t debug;              // timing experiments only (DS_DEBUG)
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
         const int64_t qbase = a.q_rowptr[q];
         const int64_t n64 = a.q_rowptr[q + 1] - qbase;
         const double maxint = a.q_maxint[q];
-        bool slow = n64 > kMaxQueryColumns || n64 < 0 || !(maxint > 0.0) || !(maxint < 1e30);
+        bool slow = a.literal_only != 0 || n64 > kMaxQueryColumns || n64 < 0 || !(maxint > 0.0) || !(maxint < 1e30);
         int reason = slow ? 0 : -1;  // why the query is handed to the dense kernel (diagnostics)
         const int n = slow ? 0 : static_cast<int>(n64);
         if (tid < n) {
@@ -1416,6 +1417,7 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     if (const char *limit = getenv("DS_SPARSE_QUADS"); limit != nullptr) args.sparse_quads = atoi(limit);
     args.sums_min = index->sums_min;
     args.debug = 0;
+    args.literal_only = index->literal_only ? 1 : 0;
     args.select_min = 64;
     args.select_growth = 4;
     if (const char *v = getenv("DS_SELECT_MIN"); v != nullptr) args.select_min = atoi(v);

@@ -144,6 +144,9 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
             postings[write++] = static_cast<uint16_t>(t % ds::kTile);
         }
     }
+    bool literal_only = false;  // the pruning bounds assume 0 <= idf, sums < inf (what match_maker.py:135-142,174 produce)
+    for (int64_t g = 0; g < V && !literal_only; ++g) literal_only = !(idf32[g] >= 0.f && idf32[g] < 1e30f);
+    for (int64_t t = 0; t < N && !literal_only; ++t) literal_only = !(sums32[t] >= 0.f && sums32[t] < 1e30f);
     DS_HIP(hipSetDevice(device));
     hipDeviceProp_t properties;
     DS_HIP(hipGetDeviceProperties(&properties, device));
@@ -156,6 +159,7 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     index->n_tiles = n_tiles;
     index->n_quads = static_cast<int64_t>(quads);
     index->sums_min = sums_min;
+    index->literal_only = literal_only;
     int status = index->col_ptr.upload(col_ptr.data(), col_ptr.size());
     if (status == DS_OK) status = index->postings.upload(postings.data(), postings.size());
     if (status == DS_OK && postings.empty()) status = index->postings.allocate(4);

@@ -220,3 +220,15 @@ def test_match_maker_from_titles_equals_dataframe_build():
     assert np.array_equal(native.get_closest_matches_batch(), reference_style.get_closest_matches_batch())
     for row in (0, 17, 299):
         assert native.get_closest_matches(row) == reference_style.get_closest_matches(row)
+
+
+def test_values_outside_the_bounds_assumptions_take_the_literal_kernel(oracle):
+    """Negative IDF values (impossible from match_maker.py:135-142, possible through the C ABI) void the pruning
+    bounds: the index then routes every query to the literal kernel and the results still match the oracle."""
+    rng = np.random.RandomState(77)
+    problem = _random_problem(rng, 20000, 600, 24)
+    problem["idf32"] = problem["idf32"].copy()
+    problem["idf32"][::7] *= -1.0
+    index = _check(oracle, problem, 10)
+    stats = index.sync()
+    assert stats["dense_queries"] == 24 and stats["error_queries"] == 0
