@@ -144,9 +144,19 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
             postings[write++] = static_cast<uint16_t>(t % ds::kTile);
         }
     }
-    bool literal_only = false;  // the pruning bounds assume 0 <= idf, sums < inf (what match_maker.py:135-142,174 produce)
+    // The pruning bounds of the fast kernel assume what match_maker.py:135-142,174 produce: 0 <= idf < inf and
+    // sums32[t] = the sum of the idf values of row t's columns (so a row's intersection score never exceeds its
+    // sums).  An index that violates this (possible through the C ABI) is served by the literal kernel only.
+    bool literal_only = false;
     for (int64_t g = 0; g < V && !literal_only; ++g) literal_only = !(idf32[g] >= 0.f && idf32[g] < 1e30f);
     for (int64_t t = 0; t < N && !literal_only; ++t) literal_only = !(sums32[t] >= 0.f && sums32[t] < 1e30f);
+    if (!literal_only) {
+        std::vector<double> row_total(static_cast<size_t>(N), 0.0);
+        for (int64_t g = 0; g < V; ++g)
+            for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) row_total[static_cast<size_t>(truth_idx[p])] += idf32[g];
+        for (int64_t t = 0; t < N && !literal_only; ++t)
+            literal_only = static_cast<double>(sums32[t]) < row_total[static_cast<size_t>(t)] * (1.0 - 1e-4);
+    }
     DS_HIP(hipSetDevice(device));
     hipDeviceProp_t properties;
     DS_HIP(hipGetDeviceProperties(&properties, device));

@@ -232,3 +232,12 @@ def test_values_outside_the_bounds_assumptions_take_the_literal_kernel(oracle):
     index = _check(oracle, problem, 10)
     stats = index.sync()
     assert stats["dense_queries"] == 24 and stats["error_queries"] == 0
+
+
+def test_inconsistent_sums_take_the_literal_kernel(oracle):
+    """sums32 smaller than a row's own idf total (again only possible through the C ABI) is detected at index build."""
+    rng = np.random.RandomState(78)
+    problem = _random_problem(rng, 20000, 600, 24)
+    problem["sums32"] = (problem["sums32"] * np.float32(0.5)).astype(np.float32)
+    index = _check(oracle, problem, 10)
+    assert index.sync()["dense_queries"] == 24
