@@ -418,6 +418,9 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
         // every reachable score.  A row's sum is at most kFixedOne + n (every term rounds by < 1 unit) < 65536, so
         // the low half of a word never carries into the high half.
         const float total_mass = uniform(n > 0 ? fmaxf(maxint32, mass_upto[n - 1]) : maxint32);
+        // the error margin below assumes maxint >= the idf total of the query's columns, as match_maker.py:197 computes
+        // it; a caller-supplied smaller value (C ABI) sends the query to the literal kernel
+        if (!slow && n > 0 && uniform(maxint32 < mass_upto[n - 1] * 0.999f)) { slow = true; reason = 0; }
         const float to_fixed = uniform(kFixedOne / total_mass), from_fixed = uniform(total_mass * (1.f / kFixedOne));
         if (tid < kMaxQueryColumns) {
             // fixed-point image of every column's IDF and the exact total of what the quantisation can be off by

@@ -241,3 +241,13 @@ def test_inconsistent_sums_take_the_literal_kernel(oracle):
     problem["sums32"] = (problem["sums32"] * np.float32(0.5)).astype(np.float32)
     index = _check(oracle, problem, 10)
     assert index.sync()["dense_queries"] == 24
+
+
+def test_small_max_intersection_takes_the_literal_kernel(oracle):
+    """max_intersection_possible below the idf total of the query's columns (not what match_maker.py:197 computes)."""
+    rng = np.random.RandomState(79)
+    problem = _random_problem(rng, 30000, 600, 32)
+    problem["q_maxint"] = problem["q_maxint"].copy()
+    problem["q_maxint"][::2] *= 0.25
+    index = _check(oracle, problem, 10)
+    assert index.sync()["dense_queries"] >= 16
