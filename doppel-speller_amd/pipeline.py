@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .feature_engineering import FEATURES_COUNT, SPACE_CODE, TitleTable
+from .feature_engineering import FEATURES_COUNT, LEVENSHTEIN_RATIO_THRESHOLD, SORT_KEY, SPACE_CODE, TitleTable
 from .match_maker import TruthIndex
 
 
@@ -37,6 +37,7 @@ class CandidatePipeline:
             rows_ptr = self._rows.ptr
         self.rows_ptr = rows_ptr if isinstance(rows_ptr, ctypes.c_void_p) else ctypes.c_void_p(int(rows_ptr))
         self.d_features = _lib.DeviceArray((self.n_queries * k, FEATURES_COUNT), np.float32, device)
+        self._close = None
 
     def enqueue_top_k(self, stream=None):
         self.index.top_k_device(self.d_rowptr.ptr, self.d_cols.ptr, self.d_maxint.ptr, self.n_queries, self.k,
@@ -47,6 +48,24 @@ class CandidatePipeline:
             self.query_titles.handle, self.truth_titles.handle, ctypes.c_void_p(0), self.rows_ptr, 0, self.k,
             SPACE_CODE, self.n_truth, self.n_queries * self.k, self.d_features.ptr, ctypes.c_void_p(stream or 0)),
             "ds_construct_features_indexed_device")
+
+    def enqueue_close_matches(self, stream=None, threshold=LEVENSHTEIN_RATIO_THRESHOLD):
+        """Next row f-1 in the same device-resident flow (predict.py:140-183): the fuzzy ratio of every (query,
+        candidate) pair and the unique best candidate per query, read from the top-k rows in HBM."""
+        if self._close is None:
+            self._close = (_lib.DeviceArray((self.n_queries, self.k), np.uint8, self.device),
+                           _lib.DeviceArray((self.n_queries,), np.int32, self.device),
+                           _lib.DeviceArray.from_host(np.ascontiguousarray(SORT_KEY, dtype=np.uint8), self.device))
+        ratios, best, sort_key = self._close
+        _lib.check(_lib.lib().ds_close_matches_device(
+            self.query_titles.handle, self.truth_titles.handle, self.rows_ptr, 0, self.k, self.n_queries, SPACE_CODE,
+            sort_key.ptr, int(threshold), ratios.ptr, best.ptr, ctypes.c_void_p(stream or 0)),
+            "ds_close_matches_device")
+
+    def close_matches(self):
+        """(ratios uint8[Q, k], best_row int32[Q]) of the last `enqueue_close_matches`."""
+        ratios, best, _ = self._close
+        return ratios.to_host(), best.to_host()
 
     def step(self, stream=None):
         self.enqueue_top_k(stream)

@@ -79,3 +79,23 @@ def test_close_matches_token_sort_and_long_titles(oracle):
     assert bad.shape[0] == 0, (bad[:5], [xs[i] for i in bad[:3]], [ys[i] for i in bad[:3]], ratios[bad[:5], 0],
                                expected[bad[:5]])
     assert np.array_equal(best, np.where(expected > 94, rows[:, 0], -1))
+
+
+def test_close_matches_inside_the_device_pipeline(oracle):
+    """The same step enqueued behind the Jaccard kernels on the top-k rows resident in HBM (no host round trip)."""
+    import doppel_speller_amd as ds
+    from doppel_speller_amd import synth
+    w = synth.make_workload(30000, 800, seed=33)
+    pipeline = ds.CandidatePipeline(w, 10)
+    pipeline.enqueue_top_k()
+    pipeline.enqueue_close_matches()
+    pipeline.enqueue_features()
+    assert pipeline.sync()["error_queries"] == 0
+    rows = pipeline.rows()
+    ratios, best = pipeline.close_matches()
+    pair_q = np.repeat(np.arange(rows.shape[0]), rows.shape[1])
+    pair_t = rows.reshape(-1)
+    expected = oracle.close_ratios(w.q_len[pair_q], w.t_len[pair_t], w.q_enc[pair_q], w.t_enc[pair_t], ds.SPACE_CODE,
+                                   ds.SORT_KEY).reshape(rows.shape)
+    assert np.array_equal(ratios, expected)
+    assert np.array_equal(best, _best_from_ratios(expected, rows, 94))
