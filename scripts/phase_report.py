@@ -8,4 +8,4 @@ values = {int(a): int(b) for a, b in re.findall(r"(\d+)=(\d+)", line)}
 total = sum(values.values())
 for i, v in sorted(values.items(), key=lambda kv: -kv[1]):
     if v:
-        print(f"{names.get(i, i):30s} {100.0 * v / total:5.1f}%")
+        print(f"{str(names.get(i, i)):30s} {100.0 * v / total:5.1f}%")
