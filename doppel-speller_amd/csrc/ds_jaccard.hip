@@ -109,8 +109,8 @@ constexpr int kProbeMaxK = kThreads / 4;  // threshold bootstrap from per-thread
 // LDS control words
 enum { kLQuery = 0, kLCount, kLOverflow, kLDigit, kLRemain, kLCoef, kLPre, kLCut, kLKth0, kLKth1, kLBad, kLItems,
        kLQuads, kLNonEssential, kLMass, kLSparse, kLSigMask /* 4 words */, kLQuant = kLSigMask + 4 /* quantisation error of the query's columns, 1/65536 units */, kLEnd,
-       kLTileMin = 24 /* kPtrTiles floats: min sums32 of the cached tiles */ };
-static_assert(kLEnd <= kLTileMin && kLTileMin + kPtrTiles <= 32, "LDS control words");
+       };
+static_assert(kLEnd <= 32, "LDS control words");
 
 // Workgroup-uniform values read from LDS or computed on the vector ALU live in VGPRs unless the compiler is told that
 // they are uniform: `uniform` moves them to scalar registers (the kernel is VGPR-bound: 128 per lane at 2 WGs/CU).
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
     uint32_t *col_total = reinterpret_cast<uint32_t *>(lds + kOffTotal);  // quads of column j over all tiles
     // mass_table[b] = upper bound of what the skipped columns add to a row whose signature bits 0..7 are b
     float *mass_table = reinterpret_cast<float *>(lds + kOffMassTable);
-    uint32_t *ptr_cache = reinterpret_cast<uint32_t *>(lds + kOffPtr);  // [column][kPtrTiles + 1]
+    uint32_t *ptr_cache = reinterpret_cast<uint32_t *>(lds + kOffPtr);  // [column][span + 1], kMaxQueryColumns * (kPtrTiles + 1) words
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + kOffHist);
     volatile int32_t *ctrl = reinterpret_cast<volatile int32_t *>(lds + kOffCtrl);
 
@@ -496,22 +496,29 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
         };
 
         int sparse_retries = 0;
+        // The list pointers of the query's columns are cached in LDS for `span` tiles at a time: as many as the cache
+        // holds for this query's number of columns (all 18 tiles of C2 for a query of up to 26 columns), so that the
+        // reload -- an exposed global latency between two barriers -- happens rarely.
+        const int span = n > 0 ? min(a.n_tiles, max(kPtrTiles, kMaxQueryColumns * (kPtrTiles + 1) / n - 1)) : kPtrTiles;
+        int block_start = 0, block_end = 0;
         for (int b = 0; b < a.n_tiles && !slow; ++b) {
-            const int bt = b % kPtrTiles;
             bool redo_tile = false;
-            if (bt == 0) {  // list pointers + min sums32 of the next kPtrTiles tiles: one coalesced burst
+            const float tile_min = a.tile_sums_min[b];  // scalar load, consumed after the item map is built
+            if (b >= block_end) {  // list pointers of the next `span` tiles: one coalesced burst
+                block_start = b;
+                block_end = b + span;
                 __syncthreads();
-                const int width = min(kPtrTiles, a.n_tiles - b) + 1;
-                for (int e = tid; e < n * (kPtrTiles + 1); e += kThreads) {
-                    const int j = e / (kPtrTiles + 1), i = e % (kPtrTiles + 1);
+                const int width = min(span, a.n_tiles - b) + 1;
+                for (int e = tid; e < n * (span + 1); e += kThreads) {
+                    const int j = e / (span + 1), i = e - j * (span + 1);
                     ptr_cache[e] = (i < width && DS_OK_INDEX(2, static_cast<int64_t>(cols[j]) * ptr_stride + b + i,
                                                             a.n_columns * ptr_stride))
                                        ? a.col_ptr[static_cast<int64_t>(cols[j]) * ptr_stride + b + i]
                                        : 0u;
                 }
-                if (tid < kPtrTiles && b + tid < a.n_tiles) ctrl[kLTileMin + tid] = __float_as_int(a.tile_sums_min[b + tid]);
                 __syncthreads();
             }
+            const int bt = b - block_start;
             bounds.mass = pending_mass;  // what this tile's scores do NOT contain; fixed until the tile is done
             skipped.count = non_essential;
             for (int w = 0; w < kSignatureWords; ++w) skipped.sig_mask[w] = pending_sig_mask[w];
@@ -541,8 +548,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 const int j = lane + 64 * h;
                 uint32_t begin = 0, end = 0;
                 if (j < n && rank[j] >= non_essential) {
-                    begin = ptr_cache[j * (kPtrTiles + 1) + bt];
-                    end = ptr_cache[j * (kPtrTiles + 1) + bt + 1];
+                    begin = ptr_cache[j * (span + 1) + bt];
+                    end = ptr_cache[j * (span + 1) + bt + 1];
                 }
                 list_first[h] = begin;
                 list_quads[h] = end - begin;
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             // row-independent gate of this tile: coef * (min sums of the tile + maxint), rounded down
             Bounds here = bounds;
             {
-                const float gate = uniform(bounds.coef * (__int_as_float(ctrl[kLTileMin + bt]) + maxint32) * (1.f - 3.814697265625e-06f));
+                const float gate = uniform(bounds.coef * (tile_min + maxint32) * (1.f - 3.814697265625e-06f));
                 if (gate > here.pre) here.pre = gate;
             }
             // A sweep only runs the register-level tests and appends RAW entries (approximate essential score, row);
@@ -925,7 +932,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 bounds.pre = uniform(__int_as_float(ctrl[kLPre]));
                 here.coef = bounds.coef;
                 {
-                    const float gate = uniform(bounds.coef * (__int_as_float(ctrl[kLTileMin + bt]) + maxint32) * (1.f - 3.814697265625e-06f));
+                    const float gate = uniform(bounds.coef * (tile_min + maxint32) * (1.f - 3.814697265625e-06f));
                     here.pre = gate > bounds.pre ? gate : bounds.pre;
                 }
                 pending_mass = uniform(__int_as_float(ctrl[kLMass]));
