@@ -109,8 +109,8 @@ constexpr int kProbeMaxK = kThreads / 4;  // threshold bootstrap from per-thread
 // LDS control words
 enum { kLQuery = 0, kLCount, kLOverflow, kLDigit, kLRemain, kLCoef, kLPre, kLCut, kLKth0, kLKth1, kLBad, kLItems,
        kLQuads, kLNonEssential, kLMass, kLSparse, kLSigMask /* 4 words */, kLQuant = kLSigMask + 4 /* quantisation error of the query's columns, 1/65536 units */, kLEnd,
-       };
-static_assert(kLEnd <= 32, "LDS control words");
+       kLStats = 24 /* 5 words: per-workgroup sums of the per-query statistics */ };
+static_assert(kLEnd <= kLStats && kLStats + 5 <= 32, "LDS control words");
 
 // Workgroup-uniform values read from LDS or computed on the vector ALU live in VGPRs unless the compiler is told that
 // they are uniform: `uniform` moves them to scalar registers (the kernel is VGPR-bound: 128 per lane at 2 WGs/CU).
@@ -351,6 +351,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
 
     for (int i = tid * 4; i < kScoreWords; i += kThreads * 4)
         *reinterpret_cast<uint4 *>(&iscores[i]) = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 5) ctrl[kLStats + tid] = 0;
     __syncthreads();
 
     for (;;) {
@@ -1089,11 +1090,12 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             for (int i = tid; i < m; i += kThreads) exact_jaccard[i] = 0.0;
             if (tid == 0) {
                 a.status[q] = kQueryDone;
-                atomicAdd(&a.control[kCtlExact], m);
-                atomicAdd(&a.control[kCtlSelects], selects);
-                atomicAdd(&a.control[kCtlSparseTiles], sparse_tiles);
-                atomicAdd(&a.control[kCtlDenseTiles], dense_tiles);
-                atomicAdd(&a.control[kCtlSkippedColumns], non_essential);
+                // statistics are summed per workgroup in LDS and reach HBM once, at the end of the kernel
+                ctrl[kLStats + 0] += m;
+                ctrl[kLStats + 1] += selects;
+                ctrl[kLStats + 2] += sparse_tiles;
+                ctrl[kLStats + 3] += dense_tiles;
+                ctrl[kLStats + 4] += non_essential;
             }
             __syncthreads();
             DS_STAMP(5);
@@ -1108,6 +1110,13 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             __syncthreads();
             DS_STAMP(0);
         }
+    }
+    if (tid == 0) {
+        atomicAdd(&a.control[kCtlExact], ctrl[kLStats + 0]);
+        atomicAdd(&a.control[kCtlSelects], ctrl[kLStats + 1]);
+        atomicAdd(&a.control[kCtlSparseTiles], ctrl[kLStats + 2]);
+        atomicAdd(&a.control[kCtlDenseTiles], ctrl[kLStats + 3]);
+        atomicAdd(&a.control[kCtlSkippedColumns], ctrl[kLStats + 4]);
     }
 #ifdef DS_DIAGNOSTICS
     if (a.phase != nullptr && tid == 0)
