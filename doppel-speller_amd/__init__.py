@@ -17,3 +17,4 @@ from .feature_engineering import (  # noqa: F401
     get_truth_words_counts, levenshtein_ratio_batch, find_close_matches, ALLOWED_CHARACTERS, SPACE_CODE, SORT_KEY)
 from .match_maker import MatchMaker, NativeProblem, TruthIndex  # noqa: F401
 from .pipeline import CandidatePipeline  # noqa: F401
+from .forest import ForestModel  # noqa: F401

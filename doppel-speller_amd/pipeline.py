@@ -38,6 +38,7 @@ class CandidatePipeline:
         self.rows_ptr = rows_ptr if isinstance(rows_ptr, ctypes.c_void_p) else ctypes.c_void_p(int(rows_ptr))
         self.d_features = _lib.DeviceArray((self.n_queries * k, FEATURES_COUNT), np.float32, device)
         self._close = None
+        self._predictions = None
 
     def enqueue_top_k(self, stream=None):
         self.index.top_k_device(self.d_rowptr.ptr, self.d_cols.ptr, self.d_maxint.ptr, self.n_queries, self.k,
@@ -66,6 +67,15 @@ class CandidatePipeline:
         """(ratios uint8[Q, k], best_row int32[Q]) of the last `enqueue_close_matches`."""
         ratios, best, _ = self._close
         return ratios.to_host(), best.to_host()
+
+    def enqueue_predict(self, model, stream=None):
+        """Next row f-4: the tree ensemble (predict.py:229-234) on the feature matrix resident in HBM."""
+        if self._predictions is None:
+            self._predictions = _lib.DeviceArray((self.n_queries * self.k,), np.float32, self.device)
+        model.predict_device(self.d_features.ptr, self.n_queries * self.k, None, self._predictions.ptr, stream)
+
+    def predictions(self):
+        return self._predictions.to_host().reshape(self.n_queries, self.k)
 
     def step(self, stream=None):
         self.enqueue_top_k(stream)

@@ -295,3 +295,22 @@ def algorithmic_bytes_jaccard(w, k):
     posting_lengths = np.diff(w.rowptr)
     touched = int(posting_lengths[w.q_cols].sum())
     return 4 * touched + w.n_queries * (4 * w.n_truth + 4 * k) + 16 * int(w.q_rowptr[-1])
+
+
+def make_forest(seed=DEFAULT_SEED, n_trees=300, depth=6, n_features=66):
+    """A random complete-binary-tree ensemble in the flat layout of `ForestModel` (bench.py's stand-in for the pickled
+    booster of predict.py:80-82: the real model file is not part of the reference tree)."""
+    rng = np.random.RandomState(seed)
+    size = 2 ** (depth + 1) - 1
+    inner = 2 ** depth - 1
+    feature = np.full((n_trees, size), -1, dtype=np.int32)
+    feature[:, :inner] = rng.randint(0, n_features, (n_trees, inner))
+    threshold = rng.normal(0, 0.1, (n_trees, size)).astype(np.float32)          # leaves
+    threshold[:, :inner] = rng.uniform(0, 100, (n_trees, inner)).astype(np.float32)
+    node = np.arange(size, dtype=np.int32)
+    yes = np.tile(np.where(node < inner, 2 * node + 1, 0), (n_trees, 1)).astype(np.int32)
+    no = np.tile(np.where(node < inner, 2 * node + 2, 0), (n_trees, 1)).astype(np.int32)
+    missing = np.where(rng.rand(n_trees, size) < 0.5, yes, no).astype(np.int32)
+    return dict(feature=feature.reshape(-1), threshold=threshold.reshape(-1), yes=yes.reshape(-1), no=no.reshape(-1),
+                missing=missing.reshape(-1), tree_offsets=np.arange(n_trees + 1, dtype=np.int64) * size,
+                base_margin=0.0, n_features=n_features)

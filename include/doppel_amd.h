@@ -41,6 +41,7 @@ typedef struct ds_index ds_index;   /* truth inverted index resident in HBM (Mat
 typedef struct ds_titles ds_titles; /* table of encoded titles resident in HBM */
 typedef struct ds_timer ds_timer;   /* pair of HIP events */
 typedef struct ds_problem ds_problem; /* host-side product of the native index build (next row f-3) */
+typedef struct ds_forest ds_forest;   /* tree ensemble resident in HBM (next row f-4) */
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */
 const char *ds_last_error(void);
@@ -139,6 +140,22 @@ int ds_problem_info(const ds_problem *problem, int64_t info[8]);
 int ds_problem_arrays(const ds_problem *problem, const uint32_t **vocabulary, const float **idf32, const double **idf64,
                       const int64_t **rowptr, const int32_t **truth_idx, const float **sums32, const int64_t **q_rowptr,
                       const int32_t **q_cols, const double **q_maxint);
+
+/* ---- next row f-4: tree-ensemble scoring of the feature matrix -----------------------------------------------------
+ * Replaces xgb.DMatrix(features) + model.predict(features_d, ntree_limit=...) (doppelspeller/predict.py:229-234) for a
+ * `binary:logistic` booster, on the float32[n, n_features] matrix that ds_construct_features_* left in HBM.  Nodes of
+ * all trees are concatenated; tree t owns nodes [tree_offsets[t], tree_offsets[t + 1]); child ids are tree-relative
+ * (xgboost's nodeid); feature[i] < 0 marks a leaf whose value is threshold[i]; a NaN feature follows `missing`,
+ * value < threshold follows `yes`, else `no`.  base_margin = logit(base_score).  Pass only the first
+ * best_ntree_limit trees to reproduce `ntree_limit`.  Either output pointer may be NULL.
+ * xgboost is outside the reference tree: the published rule is restated, parity unpinned. */
+int ds_forest_create(const int32_t *feature, const float *threshold, const int32_t *yes, const int32_t *no,
+                     const int32_t *missing, const int64_t *tree_offsets, int32_t n_trees, int32_t n_features,
+                     float base_margin, int device, ds_forest **out);
+void ds_forest_destroy(ds_forest *forest);
+int ds_forest_predict(ds_forest *forest, const float *rows, int64_t n, float *margins, float *probabilities);
+int ds_forest_predict_device(ds_forest *forest, const float *d_rows, int64_t n, float *d_margins,
+                             float *d_probabilities, void *stream);
 
 /* ---- device memory / stream / timing plumbing (so tests and bench.py can keep inputs resident in HBM) ----------- */
 int ds_malloc(void **ptr, size_t bytes, int device);

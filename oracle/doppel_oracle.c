@@ -398,3 +398,42 @@ void ds_oracle_close_ratios(const uint8_t *x_len, const uint8_t *y_len, const ui
         out[i] = (uint8_t)ds_oracle_close_ratio(x + i * stride, x_len[i], y + i * stride, y_len[i], space, sort_key,
                                                 threshold);
 }
+
+/* ---- next row f-4: gradient-boosted tree ensemble on the 66 features (predict.py:229-234) -------------------------
+ * xgboost (requirements.txt) is not part of the reference tree and not installable here: what follows restates the
+ * PUBLISHED prediction rule of an xgboost `binary:logistic` booster on a dense float32 matrix with missing = NaN
+ * (xgb.DMatrix(features), predict.py:229): per tree, from the root: a missing value follows the node's `missing`
+ * child, otherwise value < split_condition follows `yes`, else `no`; the leaf values of the first n_trees trees
+ * are added in tree order in float32 to the base margin; the prediction is 1 / (1 + exp(-margin)).  Parity unpinned
+ * against the real library.  Node layout: feature < 0 marks a leaf whose value is in `threshold`. */
+float ds_oracle_forest_margin(const int32_t *feature, const float *threshold, const int32_t *yes, const int32_t *no,
+                              const int32_t *missing, const int64_t *tree_offsets, int32_t n_trees, float base_margin,
+                              const float *row)
+{
+    float margin = base_margin;
+    for (int32_t t = 0; t < n_trees; ++t) {
+        int64_t node = tree_offsets[t];
+        while (feature[node] >= 0) {
+            const float value = row[feature[node]];
+            int32_t next;
+            if (value != value) next = missing[node];
+            else next = value < threshold[node] ? yes[node] : no[node];
+            node = tree_offsets[t] + next;
+        }
+        margin = margin + threshold[node];
+    }
+    return margin;
+}
+
+void ds_oracle_forest_predict(const int32_t *feature, const float *threshold, const int32_t *yes, const int32_t *no,
+                              const int32_t *missing, const int64_t *tree_offsets, int32_t n_trees, float base_margin,
+                              const float *rows, int64_t n, int64_t n_features, float *margins, float *probabilities)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const float margin = ds_oracle_forest_margin(feature, threshold, yes, no, missing, tree_offsets, n_trees,
+                                                     base_margin, rows + i * n_features);
+        if (margins) margins[i] = margin;
+        if (probabilities) probabilities[i] = 1.0f / (1.0f + expf(-margin));
+    }
+}

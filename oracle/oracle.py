@@ -158,3 +158,24 @@ def close_ratios(x_len, y_len, x_enc, y_enc, space_code, sort_key, threshold=94)
                                  _ptr(sort_key, ctypes.c_uint8), ctypes.c_int32(int(threshold)),
                                  _ptr(out, ctypes.c_uint8))
     return out
+
+
+def forest_predict(forest, rows):
+    """xgboost binary:logistic prediction restated (parity unpinned): (margins float32[n], probabilities float32[n]).
+    forest: dict with feature/yes/no/missing int32[nodes], threshold float32[nodes], tree_offsets int64[T + 1],
+    base_margin float."""
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    n = rows.shape[0]
+    margins = np.empty(n, dtype=np.float32)
+    probabilities = np.empty(n, dtype=np.float32)
+    arrays = {name: np.ascontiguousarray(forest[name], dtype=dtype) for name, dtype in
+              (("feature", np.int32), ("threshold", np.float32), ("yes", np.int32), ("no", np.int32),
+               ("missing", np.int32), ("tree_offsets", np.int64))}
+    lib().ds_oracle_forest_predict(
+        _ptr(arrays["feature"], ctypes.c_int32), _ptr(arrays["threshold"], ctypes.c_float),
+        _ptr(arrays["yes"], ctypes.c_int32), _ptr(arrays["no"], ctypes.c_int32),
+        _ptr(arrays["missing"], ctypes.c_int32), _ptr(arrays["tree_offsets"], ctypes.c_int64),
+        ctypes.c_int32(arrays["tree_offsets"].shape[0] - 1), ctypes.c_float(float(forest["base_margin"])),
+        _ptr(rows, ctypes.c_float), ctypes.c_int64(n), ctypes.c_int64(rows.shape[1]),
+        _ptr(margins, ctypes.c_float), _ptr(probabilities, ctypes.c_float))
+    return margins, probabilities
