@@ -18,3 +18,4 @@ from .feature_engineering import (  # noqa: F401
 from .match_maker import MatchMaker, NativeProblem, TruthIndex  # noqa: F401
 from .pipeline import CandidatePipeline  # noqa: F401
 from .forest import ForestModel  # noqa: F401
+from .text import transform_title, transform_titles  # noqa: F401

@@ -60,6 +60,7 @@ def _declare(handle):
         "ds_problem_create": [p, p, c.c_int64, p, p, c.c_int64, c.c_int32, c.POINTER(p)],
         "ds_problem_info": [p, c.POINTER(c.c_int64)],
         "ds_problem_arrays": [p] + [c.POINTER(p)] * 9,
+        "ds_transform_titles": [p, p, c.c_int64, c.c_int32, c.c_int32, p, p],
         "ds_forest_create": [p, p, p, p, p, p, c.c_int32, c.c_int32, c.c_float, c.c_int, c.POINTER(p)],
         "ds_forest_predict": [p, p, c.c_int64, p, p],
         "ds_forest_predict_device": [p, p, c.c_int64, p, p, p],
@@ -90,7 +91,7 @@ EXPORTED_SYMBOLS = (
     "ds_index_info", "ds_jaccard_topk", "ds_jaccard_topk_device", "ds_jaccard_sync", "ds_construct_features",
     "ds_titles_create", "ds_titles_destroy", "ds_construct_features_indexed", "ds_construct_features_indexed_device",
     "ds_levenshtein_ratio_batch", "ds_close_matches", "ds_close_matches_device", "ds_problem_create",
-    "ds_problem_destroy", "ds_problem_info", "ds_problem_arrays", "ds_forest_create", "ds_forest_destroy",
+    "ds_problem_destroy", "ds_problem_info", "ds_problem_arrays", "ds_transform_titles", "ds_forest_create", "ds_forest_destroy",
     "ds_forest_predict", "ds_forest_predict_device", "ds_malloc", "ds_free", "ds_memcpy_h2d", "ds_memcpy_d2h", "ds_memset",
     "ds_stream_sync", "ds_timer_create", "ds_timer_destroy", "ds_timer_start", "ds_timer_stop",
     "ds_timer_elapsed_ms")

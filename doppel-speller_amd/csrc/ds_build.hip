@@ -208,3 +208,45 @@ int ds_problem_arrays(const ds_problem *problem, const uint32_t **vocabulary, co
 }
 
 }  // extern "C"
+
+// ---- transform_title (doppelspeller/common.py:20-47) for a batch of titles ----------------------------------------
+// The caller has already applied the Unicode part (NFD normalisation, ASCII encoding with 'ignore': Python's
+// unicodedata, identity for ASCII titles); what remains is byte work: lower case, '-' -> ' ', keep [a-zA-Z0-9\s],
+// collapse runs of ' ' (other white space is kept as it is, as SUBSTITUTE_REGEX = ' +' does), strip, cut to
+// max_characters and strip again, left-pad with '0' to n_gram characters when the title was shorter than that.
+extern "C" int ds_transform_titles(const uint8_t *chars, const int64_t *offsets, int64_t n, int32_t max_characters,
+                                   int32_t n_gram, uint8_t *out_chars, int64_t *out_offsets)
+{
+    DS_REQUIRE(offsets && out_offsets && (n == 0 || (chars && out_chars)), "ds_transform_titles: null pointer");
+    DS_REQUIRE(max_characters >= 1 && n_gram >= 0 && n_gram <= max_characters, "ds_transform_titles: bad limits");
+    auto is_space = [](uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); };  // str.isspace, ASCII
+    std::vector<uint8_t> text;
+    int64_t write = 0;
+    out_offsets[0] = 0;
+    for (int64_t t = 0; t < n; ++t) {
+        DS_REQUIRE(offsets[t + 1] >= offsets[t], "ds_transform_titles: bad offsets at %lld", (long long)t);
+        text.clear();
+        for (int64_t i = offsets[t]; i < offsets[t + 1]; ++i) {
+            uint8_t c = chars[i];
+            DS_REQUIRE(c < 128, "ds_transform_titles: title %lld is not ASCII (apply the Unicode step first)", (long long)t);
+            if (c >= 'A' && c <= 'Z') c = static_cast<uint8_t>(c + 32);
+            if (c == '-') c = ' ';
+            const bool keep = (c >= 'a' && c <= 'z') || (c >= '0' && c <= '9') || is_space(c);
+            if (!keep) continue;
+            if (c == ' ' && !text.empty() && text.back() == ' ') continue;  // ' +' -> ' '
+            text.push_back(c);
+        }
+        size_t first = 0, last = text.size();
+        while (first < last && is_space(text[first])) ++first;
+        while (last > first && is_space(text[last - 1])) --last;
+        const size_t number_of_characters = last - first;                  // :30
+        if (last - first > static_cast<size_t>(max_characters)) last = first + static_cast<size_t>(max_characters);
+        while (first < last && is_space(text[first])) ++first;             // .strip() after the cut (:31)
+        while (last > first && is_space(text[last - 1])) --last;
+        if (number_of_characters < static_cast<size_t>(n_gram))            // :33-37 rjust(n_gram, '0')
+            for (size_t pad = last - first; pad < static_cast<size_t>(n_gram); ++pad) out_chars[write++] = '0';
+        for (size_t i = first; i < last; ++i) out_chars[write++] = text[i];
+        out_offsets[t + 1] = write;
+    }
+    return DS_OK;
+}

@@ -141,6 +141,12 @@ int ds_problem_arrays(const ds_problem *problem, const uint32_t **vocabulary, co
                       const int64_t **rowptr, const int32_t **truth_idx, const float **sums32, const int64_t **q_rowptr,
                       const int32_t **q_cols, const double **q_maxint);
 
+/* transform_title (doppelspeller/common.py:20-47) for n titles whose Unicode step (NFD + ASCII encoding, Python's
+ * unicodedata) is already done: lower case, '-' -> ' ', keep [a-zA-Z0-9\s], ' +' -> ' ', strip, cut to max_characters
+ * (settings.py:68 = 255), strip, '0'-pad titles shorter than n_gram.  out_chars needs offsets[n] + n * n_gram bytes. */
+int ds_transform_titles(const uint8_t *chars, const int64_t *offsets, int64_t n, int32_t max_characters, int32_t n_gram,
+                        uint8_t *out_chars, int64_t *out_offsets);
+
 /* ---- next row f-4: tree-ensemble scoring of the feature matrix -----------------------------------------------------
  * Replaces xgb.DMatrix(features) + model.predict(features_d, ntree_limit=...) (doppelspeller/predict.py:229-234) for a
  * `binary:logistic` booster, on the float32[n, n_features] matrix that ds_construct_features_* left in HBM.  Nodes of
