@@ -601,9 +601,11 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             }
             // A sweep only runs the register-level tests and appends RAW entries (approximate essential score, row);
             // the wave refines them (flush_raw) before it leaves the tile.
+            // branch-free on purpose: short-circuit evaluation would put every LDS read of the caller behind its own
+            // exec-masked branch and wait for each one separately
             auto passes = [&](float s, float sums_lower_bound, float row_mass) {
-                return s > 0.f && s + row_mass >= here.pre &&
-                       s + row_mass >= here.coef * (sums_lower_bound + here.maxint32);
+                return (s > 0.f) & (s + row_mass >= here.pre) &
+                       (s + row_mass >= here.coef * (sums_lower_bound + here.maxint32));
             };
             // four rows at a time: one ballot decides whether anything needs appending (the common case: nothing)
             auto consider4 = [&](const uint32_t (&fixed_score)[4], const uint32_t (&local)[4],
@@ -672,9 +674,17 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                         const uint32_t info[4] = {quad_info[u].x & 0xffffu, quad_info[u].x >> 16, quad_info[u].y & 0xffffu,
                                                   quad_info[u].y >> 16};
                         uint32_t taken[4];
+                        // the four atomics of a quad are issued back to back and their results extracted afterwards
+                        // (extraction inside the same branch would wait for every atomic separately)
+                        uint32_t before[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            taken[e] = (live[u] && local[e] < kTile && !DS_DEBUG_BIT(16)) ? take_packed(iscores, local[e]) : 0u;
+                        for (int e = 0; e < 4; ++e) {
+                            before[e] = 0u;
+                            if (live[u] && local[e] < kTile && !DS_DEBUG_BIT(16))
+                                before[e] = atomicAnd(&iscores[local[e] >> 1], ~(0xffffu << ((local[e] & 1u) << 4)));
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) taken[e] = (before[e] >> ((local[e] & 1u) << 4)) & 0xffffu;
                         if (DS_DEBUG_BIT(2)) continue;
                         if (__ballot(taken[0] >= cheap_fixed || taken[1] >= cheap_fixed || taken[2] >= cheap_fixed ||
                                      taken[3] >= cheap_fixed) == 0)
