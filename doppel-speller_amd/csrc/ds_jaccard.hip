@@ -544,6 +544,9 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             // exclusive prefix of the per-column item counts in registers (lane j: columns j and j + 64), so that no
             // barrier and no LDS table is needed; item `at` belongs to the last column whose prefix is <= at.
             uint32_t list_first[2], list_quads[2], item_before[2];
+            // fixed-point IDF of columns `lane` and `lane + 64`: read by v_readlane in `locate` (an LDS read there would
+            // sit, with its wait, in front of every item's global load)
+            const uint32_t fixed_lo = fixed[lane], fixed_hi = fixed[lane + 64];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int j = lane + 64 * h;
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 }
                 first = begin + (want - prefix) * 64u + lane;
                 end = begin + quads_in_list;
-                value = uniform(fixed[j]);
+                value = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j < 64 ? fixed_lo : fixed_hi), l));
             };
             DS_STAMP(1);
 
