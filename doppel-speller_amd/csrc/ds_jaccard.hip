@@ -401,10 +401,11 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             const float mine = idf[tid];
             int r = 0;
             double below = 0.0;
-            for (int i = 0; i < n; ++i) {
+#pragma unroll 8
+            for (int i = 0; i < n; ++i) {  // unrolled: the LDS reads of eight steps are in flight together
                 const float other = idf[i];
-                const bool first = other < mine || (other == mine && i <= tid);
-                r += first && i != tid;
+                const bool first = (other < mine) | ((other == mine) & (i <= tid));
+                r += first & (i != tid);
                 below += first ? static_cast<double>(other) : 0.0;
             }
             rank[tid] = r;
