@@ -77,7 +77,8 @@ __device__ __forceinline__ void build_masks(WaveScratch &w, const uint8_t *patte
 __device__ __forceinline__ int lcs_bitparallel(const WaveScratch &w, const uint8_t *text, int n, int m)
 {
     unsigned long long v = ~0ull;
-    for (int i = 0; i < n; ++i) {
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) {  // unrolled: the two dependent LDS reads of four steps are issued ahead of the recurrence
         const unsigned long long match = w.masks[text[i]];
         const unsigned long long u = v & match;
         v = (v + u) | (v & ~match);
