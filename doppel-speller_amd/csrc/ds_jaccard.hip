@@ -760,7 +760,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     // k-th largest value of a subset of the rows, i.e. a valid lower estimate of the final k-th.
                     probed = true;
                     float best_s = 0.f, best_d = 1.f, best_sums = 0.f;
-                    for (int idx = tid * 8; idx < limit; idx += kThreads * 8) {
+#pragma unroll 2
+                    for (int idx = tid * 8; idx < limit; idx += kThreads * 8) {  // two steps' loads in flight
                         const float4 sums_lo = *reinterpret_cast<const float4 *>(&a.sums32[tile_base + idx]);
                         const float4 sums_hi = *reinterpret_cast<const float4 *>(&a.sums32[tile_base + idx + 4]);
                         const uint4 raw4 = *reinterpret_cast<uint4 *>(&iscores[idx >> 1]);
