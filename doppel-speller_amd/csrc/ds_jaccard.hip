@@ -338,7 +338,9 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
     uint32_t *iscores = reinterpret_cast<uint32_t *>(lds);  // score tile: 16-bit fixed-point sums, row r in half (r & 1) of word r >> 1
     uint32_t *col_total = reinterpret_cast<uint32_t *>(lds + kOffTotal);  // quads of column j over all tiles
     // mass_table[b] = upper bound of what the skipped columns add to a row whose signature bits 0..7 are b
-    float *mass_table = reinterpret_cast<float *>(lds + kOffMassTable);
+    // [0..255] mass16, [256..511] need16: the integer tables of the collect sweep's row test (rebuilt after a selection)
+    uint16_t *mass16 = reinterpret_cast<uint16_t *>(lds + kOffMassTable);
+    uint16_t *need16 = mass16 + 256;
     uint32_t *ptr_cache = reinterpret_cast<uint32_t *>(lds + kOffPtr);  // [column][span + 1], kMaxQueryColumns * (kPtrTiles + 1) words
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + kOffHist);
     volatile int32_t *ctrl = reinterpret_cast<volatile int32_t *>(lds + kOffCtrl);
@@ -537,7 +539,18 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     if (rest < 0.0) rest = 0.0;
                     // rounded up, and never above the full mass (which already carries its own slack)
                     const float value = round_up_positive((rest + some) * (1.0 + 3.814697265625e-06) + 1e-30);
-                    mass_table[tid] = value < bounds.mass ? value : bounds.mass;
+                    const float mass = value < bounds.mass ? value : bounds.mass;
+                    // The collect sweep tests rows in the integer domain of the fixed-point scores:
+                    //   score + mass16[signature bits 0..7] >= max(tile gate, need16[8-bit sums code])
+                    // mass16 is rounded up and need16 down by more than the float test's own roundings, so the rows
+                    // that pass are a superset of those of `passes` (no conversions, no float decoding per posting).
+                    const double unit = static_cast<double>(from_fixed);
+                    const double mass_units = static_cast<double>(mass) / unit + 2.0;
+                    mass16[tid] = static_cast<uint16_t>(mass_units < 65535.0 ? mass_units : 65535.0);
+                    const double need_units = static_cast<double>(bounds.coef) *
+                                                  (static_cast<double>(decode_sums8(tid)) + static_cast<double>(maxint32)) /
+                                                  unit - 2.0;
+                    need16[tid] = static_cast<uint16_t>(need_units < 0.0 ? 0.0 : (need_units < 65535.0 ? need_units : 65535.0));
                 }
             }
             const bool sparse = tight && sparse_mode;
@@ -665,10 +678,9 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 // Cheap integer pre-test on the taken fixed-point scores: a row can only pass `s + mass >= pre` if its
                 // score reaches (pre - mass) in fixed-point units (rounded down, minus slack: a superset of the float
                 // test).  Most quads have no such row and skip the per-row decoding and table lookups altogether.
-                const uint32_t cheap_fixed = [&]() {
-                    const double units = (static_cast<double>(here.pre) - static_cast<double>(here.mass)) /
-                                         static_cast<double>(from_fixed) * (1.0 - 1e-6) - 2.0;
-                    return units > 1.0 ? static_cast<uint32_t>(units) : 1u;
+                const uint32_t gate_fixed = [&]() {  // the tile's row-independent bound `here.pre`, rounded down
+                    const double units = static_cast<double>(here.pre) / static_cast<double>(from_fixed) - 2.0;
+                    return units > 0.0 ? static_cast<uint32_t>(units) : 0u;
                 }();
                 auto collect = [&]() {
 #pragma unroll
@@ -690,14 +702,16 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
 #pragma unroll
                         for (int e = 0; e < 4; ++e) taken[e] = (before[e] >> ((local[e] & 1u) << 4)) & 0xffffu;
                         if (DS_DEBUG_BIT(2)) continue;
-                        if (__ballot(taken[0] >= cheap_fixed || taken[1] >= cheap_fixed || taken[2] >= cheap_fixed ||
-                                     taken[3] >= cheap_fixed) == 0)
-                            continue;
-                        const float bound4[4] = {decode_sums8(info[0] >> 8), decode_sums8(info[1] >> 8),
-                                                 decode_sums8(info[2] >> 8), decode_sums8(info[3] >> 8)};
-                        const float mass4[4] = {mass_table[info[0] & 0xffu], mass_table[info[1] & 0xffu],
-                                                mass_table[info[2] & 0xffu], mass_table[info[3] & 0xffu]};
-                        consider4(taken, local, bound4, mass4);
+                        bool pass[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t have = taken[e] + mass16[info[e] & 0xffu];
+                            const uint32_t need = max(gate_fixed, static_cast<uint32_t>(need16[info[e] >> 8]));
+                            pass[e] = (taken[e] != 0u) & (have >= need);
+                        }
+                        if (__ballot(pass[0] | pass[1] | pass[2] | pass[3]) == 0) continue;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) append_raw(pass[e], taken[e], local[e]);
                     }
                 };
                 if (single_round) {
