@@ -57,3 +57,18 @@ def test_many_tiles_top50_against_oracle(oracle, big_workload):
     words = np.minimum(all_features[:, 3].astype(np.int64), 15)
     nan_expected = np.arange(15)[None, :] >= words[:, None]
     assert np.array_equal(np.isnan(all_features[:, 6:21]), nan_expected)
+
+
+def test_end_to_end_example_runs():
+    """examples/end_to_end.py: raw titles -> transform -> native index build -> top-k -> close matches -> features ->
+    tree ensemble, all through the package."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "end_to_end.py")
+    spec = importlib.util.spec_from_file_location("end_to_end_example", path)
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    rows, best_row, features, probabilities = module.main(5000, 300, 10)
+    assert rows.shape == (300, 10) and features.shape == (3000, 66) and probabilities.shape == (300, 10)
+    assert (rows >= 0).all() and (best_row >= -1).all() and ((probabilities > 0) & (probabilities < 1)).all()
+    assert (best_row >= 0).sum() > 50          # the misspelled copies are mostly caught by the fuzzy step alone
