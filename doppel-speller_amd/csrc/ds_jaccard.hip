@@ -9,15 +9,15 @@
 //                           result = the k LARGEST ROW INDEXES among {t : jaccard[t] >= threshold}, descending.
 //
 // Two kernels:
-//   ds_jaccard_topk_kernel   one 1024-thread workgroup per query pulled from a work queue.  The truth rows are
-//       visited tile by tile (32768 rows = one float32 score tile in LDS).  Scores are accumulated with order-free
-//       LDS atomics, i.e. only APPROXIMATELY (the reference's float32 rounding depends on the column order); rows
-//       whose approximate jaccard can still reach the running k-th largest value minus a rigorous error margin
-//       become candidates; a radix select over the candidate buffer tightens the running value.  Once a running
-//       value exists, columns whose total IDF cannot lift a row over it on their own ("non-essential", the
-//       MaxScore rule of top-k retrieval) are no longer traversed: their IDF mass enters the test as an upper bound.
-//       Tiles with few essential postings are handled sparsely (scatter, then an exchange sweep over the same
-//       postings that collects and re-zeroes the touched rows) instead of scanning all 32768 scores.
+//   ds_jaccard_topk_kernel   512-thread workgroups, two per CU, each pulling queries from a work queue.  The truth
+//       rows are visited tile by tile (28672 rows = one tile of 16-bit fixed-point scores, two rows per LDS word).
+//       Scores are accumulated with order-free LDS atomics, i.e. only APPROXIMATELY (the reference's float32 rounding
+//       depends on the column order); rows whose approximate jaccard can still reach the running k-th largest value
+//       minus a rigorous error margin become candidates; a radix select over the candidate buffer tightens the
+//       running value.  Once a running value exists, columns whose total IDF cannot lift a row over it on their own
+//       ("non-essential", the MaxScore rule of top-k retrieval) are no longer traversed: their IDF mass enters the
+//       test as an upper bound.  Tiles with few essential postings are handled sparsely (scatter, then a collect
+//       sweep over the same postings that takes and re-zeroes the touched rows) instead of scanning the whole tile.
 //       After the last tile the surviving candidates are evaluated EXACTLY: membership of the row in each query
 //       column's posting list by binary search, float32 sum in the reference's column order, float64 finalise, then
 //       the reference's threshold / arg-select.  Results are bit-exact; the approximation only decides where the
@@ -337,7 +337,6 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
     uint32_t *fixed = reinterpret_cast<uint32_t *>(lds + kOffFixed);  // idf[j] in the query's fixed-point scale
     uint32_t *iscores = reinterpret_cast<uint32_t *>(lds);  // score tile: 16-bit fixed-point sums, row r in half (r & 1) of word r >> 1
     uint32_t *col_total = reinterpret_cast<uint32_t *>(lds + kOffTotal);  // quads of column j over all tiles
-    // mass_table[b] = upper bound of what the skipped columns add to a row whose signature bits 0..7 are b
     // [0..255] mass16, [256..511] need16: the integer tables of the collect sweep's row test (rebuilt after a selection)
     uint16_t *mass16 = reinterpret_cast<uint16_t *>(lds + kOffMassTable);
     uint16_t *need16 = mass16 + 256;
