@@ -3,8 +3,17 @@
 Truth titles: words drawn from a Zipf(1.1) vocabulary of synthetic words over [a-z0-9] (length ~ lognormal), 1 +
 Poisson(2.5) words per title, plus a company-suffix word ("limited", "ltd", "bv", ...) on ~45 % of the titles so that
 a handful of tri-grams have posting lists covering ~27 % of the truth set (the "limited/ltd" family of the example
-data).  Queries: 60 % are a truth title with 1-2 keyboard-style edits (the recipe of
+data).  A small share of the word slots holds a word seen nowhere else (a hapax: proper names, registration numbers
+-- 18 % of the example data's word slots hold a word that occurs once; 5 % here), spelled from uniformly random
+characters: these are what lets the tri-gram vocabulary approach its 37^3 ceiling at N >= 500k, as SURVEY.md 8d
+requires.  Suffix shares follow the example data (ltd 27 %, limited 26 %, bv 16 % of the truth titles).
+Queries: 60 % are a truth title with 1-2 keyboard-style edits (the recipe of
 feature_engineering_prepare.py:90-173), 40 % are fresh titles.
+
+Measured at N = 500k (seed 20260101; SURVEY.md 8d targets in brackets): 21.2 tri-grams per title (21 +- 2), 50.3k
+tri-gram columns (~50k), postings touched per query 0.90 N (0.9 N +- 0.15 N), truth titles with a positive score per
+query 0.31 N (~0.33 N), 23.5 characters and 3.5 words per title (23.4, 3.5) -- asserted by
+tests/test_host_cpu.py::test_synthetic_workload_acceptance_at_c2_truth_size.
 
 `make_workload` returns everything both kernels consume, built the way MatchMaker.__init__ /
 FeatureEngineering.encode_title build them (match_maker.py:84-181, feature_engineering.py:298-319), with the
@@ -25,11 +34,16 @@ DEFAULT_SEED = 20260101
 _BASE = len(ALLOWED_CHARACTERS)  # 38 codes: '-'=0 (fill), ' '=1, a-z=2..27, 0-9=28..37
 _SPACE = 1
 _SUFFIXES = ("limited", "ltd", "bv", "plc", "inc", "llc", "gmbh", "company")
-_SUFFIX_WEIGHTS = np.array([0.60, 0.15, 0.06, 0.05, 0.05, 0.04, 0.03, 0.02])
+_SUFFIX_WEIGHTS = np.array([0.355, 0.37, 0.215, 0.02, 0.01, 0.01, 0.01, 0.01])
+SUFFIX_SHARE = 0.72        # example data: ltd 27.3 %, limited 26.2 %, bv 16.4 % of the truth titles
 ZIPF_OFFSET = 4.0
 SYLLABLES = 600
 RANDOM_WORD_FRACTION = 0.25
 SYLLABLE_EXPONENT = 1.2
+COMMON_SYLLABLES = 30     # the most frequent syllables are whole tri-grams ("ion", "ing", "ter" in the example data)
+SYLLABLE_OFFSET = 8.0
+HAPAX_FRACTION = 0.05      # word slots filled with a word that occurs nowhere else
+HAPAX_DIGIT_SHARE = 0.2    # characters of a hapax that are digits
 _KEYBOARD_ROWS = ("1234567890", "qwertyuiop", "asdfghjkl", "zxcvbnm")
 
 
@@ -53,10 +67,11 @@ class _Vocabulary:
         lengths = np.clip(np.rint(rng.lognormal(1.7, 0.45, size)), 1, 20).astype(np.int64)
         width = 20
         syllable_length = rng.choice([1, 2, 3], size=SYLLABLES, p=[0.15, 0.5, 0.35])
+        syllable_length[:COMMON_SYLLABLES] = 3  # "ion", "ing", "ter": the frequent syllables are whole tri-grams
         syllable_letters = rng.randint(2, 28, (SYLLABLES, 3))
         syllable_digits = rng.randint(28, 38, (SYLLABLES, 3))
         syllables = np.where(rng.rand(SYLLABLES, 3) < 0.96, syllable_letters, syllable_digits).astype(np.uint8)
-        syllable_weights = 1.0 / (np.arange(1, SYLLABLES + 1) + 3.0) ** SYLLABLE_EXPONENT
+        syllable_weights = 1.0 / (np.arange(1, SYLLABLES + 1) + SYLLABLE_OFFSET) ** SYLLABLE_EXPONENT
         syllable_cumulative = np.cumsum(syllable_weights / syllable_weights.sum())
         chars = np.zeros((size, width + 3), dtype=np.uint8)
         filled = np.zeros(size, dtype=np.int64)
@@ -96,17 +111,31 @@ class _Vocabulary:
 
 
 def _make_titles(rng, vocabulary, count):
-    """Titles as ragged arrays of word ids -> (flat codes, offsets, word ids per title as (flat, offsets))."""
+    """Titles as ragged arrays of words -> (flat codes, offsets, word ids per title as (flat, offsets), word table).
+
+    Word ids index the returned word table = the vocabulary's words followed by this call's hapaxes."""
     n_words = np.clip(1 + rng.poisson(2.5, count), 1, 20).astype(np.int64)
-    has_suffix = rng.rand(count) < 0.45
+    has_suffix = rng.rand(count) < SUFFIX_SHARE
     body_words = np.where(has_suffix & (n_words > 1), n_words - 1, n_words)
     position, row = _ragged_arange(n_words)
     word_ids = vocabulary.sample(rng, position.shape[0])
     suffix_choice = rng.choice(len(_SUFFIXES), size=count, p=_SUFFIX_WEIGHTS)
     is_suffix_slot = has_suffix[row] & (n_words[row] > 1) & (position == body_words[row])
     word_ids = np.where(is_suffix_slot, suffix_choice[row], word_ids)
+    # hapaxes: fresh words of 4..20 uniformly random characters, appended to the word table
+    hapax_slot = (rng.rand(position.shape[0]) < HAPAX_FRACTION) & ~is_suffix_slot
+    n_hapax = int(hapax_slot.sum())
+    width = vocabulary.chars.shape[1]
+    hapax_lengths = np.clip(np.rint(rng.lognormal(1.7, 0.45, n_hapax)), 4, width).astype(np.int64)
+    hapax_chars = np.where(rng.rand(n_hapax, width) < HAPAX_DIGIT_SHARE, rng.randint(28, 38, (n_hapax, width)),
+                           rng.randint(2, 28, (n_hapax, width))).astype(np.uint8)
+    hapax_chars[np.arange(width)[None, :] >= hapax_lengths[:, None]] = 0
+    word_ids = word_ids.copy()
+    word_ids[hapax_slot] = vocabulary.size + np.arange(n_hapax)
+    table_chars = np.concatenate([vocabulary.chars, hapax_chars])
+    table_lengths = np.concatenate([vocabulary.lengths, hapax_lengths])
     # keep the leading words that fit in 255 characters
-    lengths = vocabulary.lengths[word_ids]
+    lengths = table_lengths[word_ids]
     starts = np.cumsum(n_words) - n_words
     running = np.cumsum(lengths + 1)
     before = np.concatenate(([0], running))[starts]
@@ -125,8 +154,8 @@ def _make_titles(rng, vocabulary, count):
     flat = np.full(int(offsets[-1]), _SPACE, dtype=np.uint8)
     within, word_row = _ragged_arange(lengths)
     destination = (piece_start + (~first_of_title))[word_row] + within
-    flat[destination] = vocabulary.chars[word_ids[word_row], within]
-    return flat, offsets, word_ids, word_offsets
+    flat[destination] = table_chars[word_ids[word_row], within]
+    return flat, offsets, word_ids, word_offsets, table_chars
 
 
 def _to_strings(flat, offsets):
@@ -205,7 +234,7 @@ def make_workload(n_truth, n_queries, seed=DEFAULT_SEED, vocabulary_size=None, q
     """Truth titles depend on `seed` only (identical on every rank); queries on `query_seed` (default seed + 1)."""
     rng = np.random.RandomState(seed)
     vocabulary = _Vocabulary(rng, vocabulary_size or max(20000, n_truth // 25))
-    t_flat, t_off, t_words, t_word_off = _make_titles(rng, vocabulary, n_truth)
+    t_flat, t_off, t_words, t_word_off, t_word_table = _make_titles(rng, vocabulary, n_truth)
 
     # ---- queries: 60 % misspelled truth titles, 40 % fresh titles
     title_id = rng.permutation(n_truth).astype(np.int64)
@@ -216,7 +245,7 @@ def make_workload(n_truth, n_queries, seed=DEFAULT_SEED, vocabulary_size=None, q
         np.concatenate([t_flat[t_off[s]:t_off[s + 1]] for s in source]) if n_edited else np.zeros(0, np.uint8),
         np.concatenate(([0], np.cumsum(t_off[source + 1] - t_off[source]))) if n_edited else np.zeros(1, np.int64))
     edited = [_misspell(rng, title) for title in truth_strings_needed]
-    f_flat, f_off, _, _ = _make_titles(rng, vocabulary, n_queries - n_edited)
+    f_flat, f_off, _, _, _ = _make_titles(rng, vocabulary, n_queries - n_edited)
     fresh = _to_strings(f_flat, f_off)
     order = rng.permutation(n_queries)
     query_strings = [None] * n_queries
@@ -259,8 +288,14 @@ def make_workload(n_truth, n_queries, seed=DEFAULT_SEED, vocabulary_size=None, q
     t_enc, t_len = _encode(t_flat, t_off)
     q_enc, q_len = _encode(q_flat, q_off)
     word_row = np.repeat(np.arange(n_truth, dtype=np.int64), np.diff(t_word_off))
-    pairs = np.unique(word_row * vocabulary.size + t_words)
-    word_df = np.bincount(pairs % vocabulary.size, minlength=vocabulary.size)   # common.py:140-142
+    # the reference counts words as strings (common.py:140-142): two hapaxes spelled alike are one word
+    used, t_words = np.unique(t_words, return_inverse=True)
+    spelled = np.ascontiguousarray(t_word_table[used]).view(np.dtype((np.void, t_word_table.shape[1]))).reshape(-1)
+    _, canonical = np.unique(spelled, return_inverse=True)
+    t_words = canonical[t_words]
+    n_distinct_words = int(canonical.max()) + 1 if canonical.shape[0] else 0
+    pairs = np.unique(word_row * n_distinct_words + t_words)
+    word_df = np.bincount(pairs % n_distinct_words, minlength=n_distinct_words)
     slot, _ = _ragged_arange(np.diff(t_word_off))
     first = slot < NUMBER_OF_WORDS_FEATURES
     t_counts = np.zeros((n_truth, NUMBER_OF_WORDS_FEATURES), dtype=np.uint32)
@@ -275,12 +310,13 @@ def make_workload(n_truth, n_queries, seed=DEFAULT_SEED, vocabulary_size=None, q
         t_flat=t_flat, t_off=t_off, q_flat=q_flat, q_off=q_off)
 
 
-def workload_statistics(w):
-    """The acceptance numbers of SURVEY.md section 8d for a workload."""
+def workload_statistics(w, positive_sample=0):
+    """The acceptance numbers of SURVEY.md section 8d for a workload.  `positive_sample` > 0 also measures the share
+    of truth titles with a positive score (at least one shared tri-gram) on that many evenly spaced queries."""
     posting_lengths = np.diff(w.rowptr)
     touched = posting_lengths[w.q_cols]
     per_query = np.add.reduceat(touched, w.q_rowptr[:-1][np.diff(w.q_rowptr) > 0]) if touched.shape[0] else touched
-    return {
+    stats = {
         "tri_grams_per_truth_title": float(w.rowptr[-1]) / w.n_truth,
         "tri_grams_per_query": float(w.q_rowptr[-1]) / w.n_queries,
         "columns": int(w.n_columns),
@@ -288,6 +324,16 @@ def workload_statistics(w):
         "chars_per_truth_title": float(w.t_len.mean()),
         "words_per_truth_title": float((w.t_counts > 0).sum(axis=1).mean()),
     }
+    if positive_sample > 0:
+        shares = []
+        hit = np.zeros(w.n_truth, dtype=bool)
+        for q in np.linspace(0, w.n_queries - 1, min(positive_sample, w.n_queries)).astype(np.int64):
+            hit[:] = False
+            for column in w.q_cols[w.q_rowptr[q]:w.q_rowptr[q + 1]]:
+                hit[w.truth_idx[w.rowptr[column]:w.rowptr[column + 1]]] = True
+            shares.append(hit.mean())
+        stats["positive_score_fraction"] = float(np.mean(shares))
+    return stats
 
 
 def algorithmic_bytes_jaccard(w, k):

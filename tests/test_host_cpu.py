@@ -139,9 +139,21 @@ def test_synthetic_workload_acceptance(oracle):
     stats = synth.workload_statistics(w)
     assert 19 <= stats["tri_grams_per_truth_title"] <= 23
     assert 0.75 <= stats["postings_touched_per_query_over_n"] <= 1.05
-    assert stats["columns"] <= 37 ** 3 + 38 ** 2
+    assert stats["columns"] <= 37 ** 3
     assert (np.diff(w.q_cols.astype(np.int64))[np.diff(np.repeat(np.arange(500), np.diff(w.q_rowptr))) == 0] > 0).all()
     rows = oracle.jaccard_topk(w.rowptr, w.truth_idx, w.idf32, w.sums32, w.q_rowptr, w.q_cols, w.q_maxint, 10)
     derived = w.actual_row >= 0
     recall = np.mean([w.actual_row[q] in rows[q] for q in np.nonzero(derived)[0]])
     assert 0.55 <= derived.mean() <= 0.65 and recall > 0.8
+
+
+def test_synthetic_workload_acceptance_at_c2_truth_size():
+    """SURVEY.md 8d acceptance checks of the generator at the truth size of C2 (N = 500k)."""
+    from doppel_speller_amd import synth
+    w = synth.make_workload(500000, 2000, seed=synth.DEFAULT_SEED)
+    stats = synth.workload_statistics(w, positive_sample=400)
+    assert 19 <= stats["tri_grams_per_truth_title"] <= 23            # 21 +- 2
+    assert 45000 <= stats["columns"] <= 37 ** 3                       # ~50k, ceiling 50,653
+    assert 0.75 <= stats["postings_touched_per_query_over_n"] <= 1.05  # 0.9 N +- 0.15 N
+    assert 0.28 <= stats["positive_score_fraction"] <= 0.38           # ~0.33 N
+    assert 3.3 <= stats["words_per_truth_title"] <= 3.7 and 22 <= stats["chars_per_truth_title"] <= 26
