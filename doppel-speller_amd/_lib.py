@@ -1,6 +1,8 @@
 """ctypes binding of libdoppel_amd.so (C ABI: include/doppel_amd.h).  Fails loudly when the library is missing."""
 import ctypes
+import hashlib
 import os
+import re
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -18,17 +20,44 @@ def library_path():
     return os.environ.get("DS_LIBRARY") or os.path.join(_HERE, "libdoppel_amd.so")
 
 
+def source_id():
+    """First 16 hex digits of the SHA-256 over csrc/* and include/* (name + contents, names ascending): the identity
+    baked into the library as ds_build_id().  None when the sources are not next to the package."""
+    files = []
+    for directory in (os.path.join(_HERE, "csrc"), os.path.join(_ROOT, "include")):
+        if not os.path.isdir(directory):
+            return None
+        files += [os.path.join(directory, name) for name in sorted(os.listdir(directory))
+                  if name.endswith((".hip", ".h"))]
+    digest = hashlib.sha256()
+    for path in files:
+        digest.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as handle:
+            digest.update(handle.read())
+        digest.update(b"\0")
+    return digest.hexdigest()[:16]
+
+
+def binary_id(path):
+    """The id baked into an existing library, read from its bytes (no dlopen); None when absent."""
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as handle:
+        found = re.search(rb"DS_BUILD_ID=([0-9a-f]{16}|unidentified)\0", handle.read())
+    return found.group(1).decode() if found else None
+
+
 def build_library(force=False, verbose=False):
-    """Compile csrc/*.hip for gfx950 into libdoppel_amd.so next to this file (hipcc cross-compiles without a GPU)."""
+    """Compile csrc/*.hip for gfx950 into libdoppel_amd.so next to this file (hipcc cross-compiles without a GPU).
+    Rebuilds whenever the id baked into the existing binary differs from the sources' (not on mtimes)."""
     sources = [os.path.join(_HERE, "csrc", name) for name in _SOURCES]
-    headers = [os.path.join(_HERE, "csrc", "ds_common.h"), os.path.join(_ROOT, "include", "doppel_amd.h")]
     target = library_path()
-    if not force and os.path.exists(target):
-        newest = max(os.path.getmtime(path) for path in sources + headers)
-        if os.path.getmtime(target) >= newest:
-            return target
+    wanted = source_id()
+    if not force and binary_id(target) == wanted:
+        return target
     command = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-I", os.path.join(_ROOT, "include"), "-o", target] + os.environ.get("DS_BUILD_FLAGS", "").split() + sources
+               f'-DDS_BUILD_ID="{wanted}"', "-I", os.path.join(_ROOT, "include"), "-o", target] + \
+        os.environ.get("DS_BUILD_FLAGS", "").split() + sources
     if verbose:
         print(" ".join(command))
     subprocess.check_call(command)
@@ -40,6 +69,8 @@ def _declare(handle):
     p = c.c_void_p
     handle.ds_last_error.restype = c.c_char_p
     handle.ds_last_error.argtypes = []
+    handle.ds_build_id.restype = c.c_char_p
+    handle.ds_build_id.argtypes = []
     signatures = {
         "ds_version": [],
         "ds_device_count": [c.POINTER(c.c_int)],
@@ -87,7 +118,7 @@ def _declare(handle):
 
 
 EXPORTED_SYMBOLS = (
-    "ds_last_error", "ds_version", "ds_device_count", "ds_device_name", "ds_index_create", "ds_index_destroy",
+    "ds_last_error", "ds_version", "ds_build_id", "ds_device_count", "ds_device_name", "ds_index_create", "ds_index_destroy",
     "ds_index_info", "ds_jaccard_topk", "ds_jaccard_topk_device", "ds_jaccard_sync", "ds_construct_features",
     "ds_titles_create", "ds_titles_destroy", "ds_construct_features_indexed", "ds_construct_features_indexed_device",
     "ds_levenshtein_ratio_batch", "ds_close_matches", "ds_close_matches_device", "ds_problem_create",
@@ -106,7 +137,26 @@ def lib():
             raise DoppelError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  doppel-speller_amd has no CPU fallback.")
-        _lib = _declare(ctypes.CDLL(path))
+        sources = source_id()
+        if sources is not None and binary_id(path) != sources and os.environ.get("DS_ALLOW_STALE_LIBRARY") != "1":
+            # never run a binary that does not match the sources next to it: rebuild it where hipcc exists (same
+            # image on the GPU box), refuse it otherwise
+            import shutil
+            import sys
+            if os.environ.get("DS_AUTO_REBUILD", "1") != "0" and shutil.which("hipcc") and "DS_LIBRARY" not in os.environ:
+                print(f"doppel-speller_amd: {path} was built from other sources ({binary_id(path)} != {sources}); "
+                      "rebuilding", file=sys.stderr, flush=True)
+                build_library(force=True)
+            else:
+                raise DoppelError(
+                    f"{path} was built from sources {binary_id(path)}, but csrc/ + include/ are now {sources}: rebuild "
+                    "it (`python -c 'import __graft_entry__ as g; g.build()'`); a stale library is refused, not used.")
+        handle = _declare(ctypes.CDLL(path))
+        if sources is not None and handle.ds_build_id().decode() != sources and \
+                os.environ.get("DS_ALLOW_STALE_LIBRARY") != "1":
+            raise DoppelError(f"{path}: ds_build_id() = {handle.ds_build_id().decode()} does not match the sources "
+                              f"({sources})")
+        _lib = handle
     return _lib
 
 

@@ -30,7 +30,14 @@ extern "C" {
 
 const char *ds_last_error(void) { return ds::g_last_error.c_str(); }
 
-int ds_version(void) { return 100; }
+int ds_version(void) { return 200; }
+
+#ifndef DS_BUILD_ID
+#define DS_BUILD_ID "unidentified"
+#endif
+// the marker prefix lets the build script read the id of an existing binary without loading it
+static const char kBuildIdMarker[] = "DS_BUILD_ID=" DS_BUILD_ID;
+const char *ds_build_id(void) { return kBuildIdMarker + 12; }
 
 int ds_device_count(int *count)
 {

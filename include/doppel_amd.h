@@ -46,6 +46,10 @@ typedef struct ds_forest ds_forest;   /* tree ensemble resident in HBM (next row
 /* ---- library ---------------------------------------------------------------------------------------------------- */
 const char *ds_last_error(void);
 int ds_version(void);
+/* Identity of the sources this binary was compiled from: the first 16 hex digits of the SHA-256 over the files of
+ * csrc/ and include/ (name and contents, names ascending), passed by the build as -DDS_BUILD_ID.  The Python loader
+ * refuses a library whose id differs from the sources next to it (a stale .so cannot pass for a current one). */
+const char *ds_build_id(void);
 int ds_device_count(int *count);
 int ds_device_name(int device, char *name, size_t capacity);
 

@@ -157,3 +157,14 @@ def test_synthetic_workload_acceptance_at_c2_truth_size():
     assert 0.75 <= stats["postings_touched_per_query_over_n"] <= 1.05  # 0.9 N +- 0.15 N
     assert 0.28 <= stats["positive_score_fraction"] <= 0.38           # ~0.33 N
     assert 3.3 <= stats["words_per_truth_title"] <= 3.7 and 22 <= stats["chars_per_truth_title"] <= 26
+
+
+def test_library_is_tied_to_its_sources(monkeypatch):
+    """ds_build_id() is the hash of csrc/ + include/ the binary was compiled from; the loader refuses a mismatch."""
+    from doppel_speller_amd import _lib
+    assert _lib.lib().ds_build_id().decode() == _lib.source_id() == _lib.binary_id(_lib.library_path())
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "source_id", lambda: "0123456789abcdef")
+    monkeypatch.setenv("DS_AUTO_REBUILD", "0")
+    with pytest.raises(_lib.DoppelError, match="stale library is refused"):
+        _lib.lib()
