@@ -77,6 +77,7 @@ def _declare(handle):
         "ds_device_name": [c.c_int, c.c_char_p, c.c_size_t],
         "ds_index_create": [p, p, p, p, c.c_int64, c.c_int64, c.c_int, c.POINTER(p)],
         "ds_index_info": [p, c.POINTER(c.c_int64)],
+        "ds_index_duplicate_ranks": [p, p, p, c.c_int64, c.c_int64, p],
         "ds_jaccard_topk": [p, p, p, p, c.c_int64, c.c_int32, p],
         "ds_jaccard_topk_device": [p, p, p, p, c.c_int64, c.c_int32, p, p],
         "ds_jaccard_sync": [p, p, c.POINTER(c.c_int64)],
@@ -119,6 +120,7 @@ def _declare(handle):
 
 EXPORTED_SYMBOLS = (
     "ds_last_error", "ds_version", "ds_build_id", "ds_device_count", "ds_device_name", "ds_index_create", "ds_index_destroy",
+    "ds_index_duplicate_ranks",
     "ds_index_info", "ds_jaccard_topk", "ds_jaccard_topk_device", "ds_jaccard_sync", "ds_construct_features",
     "ds_titles_create", "ds_titles_destroy", "ds_construct_features_indexed", "ds_construct_features_indexed_device",
     "ds_levenshtein_ratio_batch", "ds_close_matches", "ds_close_matches_device", "ds_problem_create",

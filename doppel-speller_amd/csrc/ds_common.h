@@ -55,9 +55,22 @@ inline uint32_t encode_sums8(float x)
     return (static_cast<uint32_t>(exponent) << 4) | ((bits >> 19) & 0xfu);
 }
 
+// splitmix64 finaliser: a bijective 64-bit mixer (row-set hashes of the index build)
+inline uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+
 enum QueryStatus : int32_t { kQueryDone = 0, kQuerySlow = 1, kQueryErrorTopN = 2, kQueryErrorArg = 3 };
 
 void set_error(const char *format, ...);
+void duplicate_ranks(const int64_t *rowptr, const int32_t *truth_idx, const float *sums32, int64_t V, int64_t N,
+                     uint16_t *rank_out);
 int hip_failed(hipError_t error, const char *what, const char *file, int line);
 
 #define DS_HIP(call)                                                          \
@@ -121,6 +134,7 @@ struct ds_index {
     ds::DeviceBuffer<float> tile_sums_min; // [n_tiles] min(sums32) over the rows of each tile
     ds::DeviceBuffer<uint32_t> signature;  // [n_truth][4] bit g = row is in the posting list of the g-th densest column
     ds::DeviceBuffer<int8_t> sig_column;   // [n_columns] signature bit of a column, -1 for all but the 128 densest
+    ds::DeviceBuffer<uint16_t> dup_rank;   // [n_truth] rows with the same column set and sums32 bits but a larger index (saturating)
     ds::DeviceBuffer<double> slow_scratch; // [kSlowSlots][n_truth] float64 jaccard rows of the exact dense kernel
     ds::DeviceBuffer<uint32_t> slow_keys;  // [kSlowSlots][slow_keys_cap] compacted float32 keys (radix passes 3 and 4)
     int64_t slow_keys_cap = 0;

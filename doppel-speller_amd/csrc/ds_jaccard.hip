@@ -41,6 +41,7 @@ struct JaccardArgs {
     const float *tile_sums_min;
     const uint4 *signature;
     const int8_t *sig_column;
+    const uint16_t *dup_rank;
     const int64_t *q_rowptr;
     const int32_t *q_cols;
     const double *q_maxint;
@@ -480,7 +481,10 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 if (DS_OK_INDEX(1, t, a.n_truth)) {
                     const float sums = a.sums32[t];
                     const uint4 signature = skipped.count > 0 ? a.signature[t] : make_uint4(0u, 0u, 0u, 0u);
-                    if (may_qualify(raw, sums, bounds)) {
+                    // a row with k or more twins (same column set, same sums32) of larger index can never be among the
+                    // k largest row indexes of match_maker.py:71, and the k-th largest value does not need it either
+                    const bool shadowed = static_cast<int>(a.dup_rank[t]) >= k;
+                    if (!shadowed && may_qualify(raw, sums, bounds)) {
                         const float full = complete_score(raw, signature, skipped, bit_idf);
                         ok = candidate_key(full, sums, bounds, key);
                     }
@@ -1441,6 +1445,7 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     args.tile_sums_min = index->tile_sums_min.ptr;
     args.signature = reinterpret_cast<const uint4 *>(index->signature.ptr);
     args.sig_column = index->sig_column.ptr;
+    args.dup_rank = index->dup_rank.ptr;
     args.q_rowptr = d_q_rowptr;
     args.q_cols = d_q_cols;
     args.q_maxint = d_q_maxint;

@@ -24,6 +24,82 @@ int hip_failed(hipError_t error, const char *what, const char *file, int line)
     return DS_E_HIP;
 }
 
+// Duplicate ranks ("ties"): truth rows with the same column set and the same sums32 bits have the
+// same jaccard for EVERY query; rank[t] = how many such rows have a larger row index than t (saturating at 65535).
+// fast_arg_top_k returns the k largest row indexes at or above its threshold (match_maker.py:71), so a row with
+// rank >= k can never be returned, and leaving it out does not move the k-th largest value either (k of its twins
+// stay in).  Rows are grouped by a 128-bit hash of their column set from the last row down; a group member counts only
+// after its column list has been compared with the group's first row: a hash collision leaves the row's rank at 0,
+// which is always safe (a rank may under-count, never over-count).
+void duplicate_ranks(const int64_t *rowptr, const int32_t *truth_idx, const float *sums32, int64_t V, int64_t N,
+                     uint16_t *rank_out)
+{
+    std::vector<uint64_t> hash_a(static_cast<size_t>(N), 0u), hash_b(static_cast<size_t>(N), 0u);
+    std::vector<uint32_t> row_columns(static_cast<size_t>(N), 0u);
+    for (int64_t g = 0; g < V; ++g) {
+        const uint64_t image_a = mix64(static_cast<uint64_t>(g) + 0x9e3779b97f4a7c15ull);
+        const uint64_t image_b = mix64(static_cast<uint64_t>(g) * 0xd6e8feb86659fd93ull + 0x2545f4914f6cdd1dull);
+        for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
+            const size_t t = static_cast<size_t>(truth_idx[p]);
+            hash_a[t] += image_a;
+            hash_b[t] += image_b;
+            ++row_columns[t];
+        }
+    }
+    struct Slot { uint64_t a, b; uint32_t bits; int32_t first; };
+    size_t capacity = 16;
+    while (capacity < static_cast<size_t>(N) * 2) capacity <<= 1;
+    std::vector<Slot> table(capacity, Slot{0u, 0u, 0u, -1});
+    std::vector<int32_t> group_first(static_cast<size_t>(N), -1);  // row -> first (largest) row of its hash group
+    int64_t grouped_columns = 0;
+    for (int64_t t = N - 1; t >= 0; --t) {
+        uint32_t bits;
+        std::memcpy(&bits, &sums32[t], sizeof(bits));
+        const uint64_t a = hash_a[static_cast<size_t>(t)], b = hash_b[static_cast<size_t>(t)];
+        size_t at = static_cast<size_t>(mix64(a ^ (b << 1) ^ bits)) & (capacity - 1);
+        while (table[at].first >= 0 && !(table[at].a == a && table[at].b == b && table[at].bits == bits))
+            at = (at + 1) & (capacity - 1);
+        if (table[at].first < 0) {
+            table[at] = Slot{a, b, bits, static_cast<int32_t>(t)};
+        } else {
+            const size_t first = static_cast<size_t>(table[at].first);
+            if (group_first[first] < 0) {  // the group's first row joins with its first twin
+                group_first[first] = table[at].first;
+                grouped_columns += row_columns[first];
+            }
+            group_first[static_cast<size_t>(t)] = table[at].first;
+            grouped_columns += row_columns[static_cast<size_t>(t)];
+        }
+    }
+    // column lists of the grouped rows only (row-major; a row's columns arrive in ascending order)
+    std::vector<int64_t> list_begin(static_cast<size_t>(N) + 1, 0);
+    for (int64_t t = 0; t < N; ++t)
+        list_begin[static_cast<size_t>(t) + 1] =
+            list_begin[static_cast<size_t>(t)] + (group_first[static_cast<size_t>(t)] >= 0 ? row_columns[static_cast<size_t>(t)] : 0u);
+    std::vector<int32_t> lists(static_cast<size_t>(grouped_columns));
+    {
+        std::vector<int64_t> fill(list_begin.begin(), list_begin.end() - 1);
+        for (int64_t g = 0; g < V; ++g)
+            for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
+                const size_t t = static_cast<size_t>(truth_idx[p]);
+                if (group_first[t] >= 0) lists[static_cast<size_t>(fill[t]++)] = static_cast<int32_t>(g);
+            }
+    }
+    std::vector<uint32_t> twins(static_cast<size_t>(N), 0u);  // per group (at its first row): verified members so far
+    for (int64_t t = N - 1; t >= 0; --t) {
+        rank_out[t] = 0;
+        const int32_t first = group_first[static_cast<size_t>(t)];
+        if (first < 0 || first == t) continue;
+        const int64_t mine = list_begin[static_cast<size_t>(t)], theirs = list_begin[static_cast<size_t>(first)];
+        const uint32_t length = row_columns[static_cast<size_t>(t)];
+        if (length != row_columns[static_cast<size_t>(first)] ||
+            !std::equal(lists.begin() + mine, lists.begin() + mine + length, lists.begin() + theirs))
+            continue;  // a hash collision: the row keeps rank 0
+        const uint32_t rank = ++twins[static_cast<size_t>(first)];  // the group's first row + the twins before this one
+        rank_out[t] = static_cast<uint16_t>(std::min<uint32_t>(rank, 0xffffu));
+    }
+}
+
 }  // namespace ds
 
 extern "C" {
@@ -164,6 +240,8 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
         for (int64_t t = 0; t < N && !literal_only; ++t)
             literal_only = static_cast<double>(sums32[t]) < row_total[static_cast<size_t>(t)] * (1.0 - 1e-4);
     }
+    std::vector<uint16_t> dup_rank(static_cast<size_t>(N), 0u);
+    ds::duplicate_ranks(rowptr, truth_idx, sums32, V, N, dup_rank.data());
     DS_HIP(hipSetDevice(device));
     hipDeviceProp_t properties;
     DS_HIP(hipGetDeviceProperties(&properties, device));
@@ -191,6 +269,7 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     if (status == DS_OK) status = index->tile_sums_min.upload(tile_sums_min.data(), tile_sums_min.size());
     if (status == DS_OK) status = index->signature.upload(signature.data(), signature.size());
     if (status == DS_OK) status = index->sig_column.upload(sig_column.data(), sig_column.size());
+    if (status == DS_OK) status = index->dup_rank.upload(dup_rank.data(), dup_rank.size());
     index->slow_slots = static_cast<int>(std::max<int64_t>(
         ds::kSlowSlotsMin, std::min<int64_t>(ds::kSlowSlotsMax, ds::kSlowScratchBytes / (8 * N))));
     if (status == DS_OK) status = index->slow_scratch.allocate(static_cast<size_t>(index->slow_slots) * N);
@@ -209,6 +288,20 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
         return status;
     }
     *out = index;
+    return DS_OK;
+}
+
+int ds_index_duplicate_ranks(const int64_t *rowptr, const int32_t *truth_idx, const float *sums32, int64_t V, int64_t N,
+                             uint16_t *rank_out)
+{
+    DS_REQUIRE(rowptr && sums32 && rank_out && V > 0 && N > 0, "ds_index_duplicate_ranks: bad argument");
+    DS_REQUIRE(rowptr[0] == 0 && (rowptr[V] == 0 || truth_idx), "ds_index_duplicate_ranks: bad rowptr / truth_idx");
+    for (int64_t g = 0; g < V; ++g) {
+        DS_REQUIRE(rowptr[g + 1] >= rowptr[g], "ds_index_duplicate_ranks: rowptr not monotone");
+        for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p)
+            DS_REQUIRE(truth_idx[p] >= 0 && truth_idx[p] < N, "ds_index_duplicate_ranks: row index outside [0, N)");
+    }
+    ds::duplicate_ranks(rowptr, truth_idx, sums32, V, N, rank_out);
     return DS_OK;
 }
 
@@ -232,7 +325,7 @@ int ds_index_info(const ds_index *index, int64_t info[8])
     info[3] = ds::kTile;
     info[4] = index->n_tiles;
     info[5] = static_cast<int64_t>(index->col_ptr.bytes() + index->postings.bytes() + index->posting_sums.bytes() + index->idf32.bytes() +
-                                   index->sums32.bytes() + index->signature.bytes() + index->sig_column.bytes() +
+                                   index->sums32.bytes() + index->signature.bytes() + index->sig_column.bytes() + index->dup_rank.bytes() +
                                    index->slow_scratch.bytes() + index->slow_keys.bytes());
     info[6] = index->n_quads * 4;
     info[7] = 0;

@@ -60,6 +60,11 @@ int ds_device_name(int device, char *name, size_t capacity);
 int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float *idf32, const float *sums32,
                     int64_t V, int64_t N, int device, ds_index **out);
 void ds_index_destroy(ds_index *index);
+/* Host-only part of ds_index_create, exported for tests: rank_out[t] = number of truth rows with the same column set
+ * and the same sums32 bits as row t but a larger row index (saturating at 65535).  fast_arg_top_k returns the k
+ * LARGEST ROW INDEXES at or above its threshold (match_maker.py:71): a row of rank >= k can never be returned. */
+int ds_index_duplicate_ranks(const int64_t *rowptr, const int32_t *truth_idx, const float *sums32, int64_t V, int64_t N,
+                             uint16_t *rank_out);
 /* info[0]=N info[1]=V info[2]=nnz info[3]=tile size info[4]=tiles info[5]=device bytes info[6]=padded postings */
 int ds_index_info(const ds_index *index, int64_t info[8]);
 

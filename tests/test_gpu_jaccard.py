@@ -116,9 +116,8 @@ def test_heavy_queries_many_columns(oracle):
     assert stats["error_queries"] == 0 and stats["dense_queries"] < 40  # handled by the fast kernel
 
 
-def test_ties_and_duplicates(oracle):
-    rng = np.random.RandomState(5)
-    problem = _random_problem(rng, 50000, 2000, 40, duplicates=6000)  # 6000 identical truth rows: massive ties
+def _tie_problem(rng, n_truth, duplicates):
+    problem = _random_problem(rng, n_truth, 2000, 40, duplicates=duplicates)  # identical truth rows: massive ties
     # make several queries equal to the duplicated row so the ties sit at the top
     first = problem["truth_idx"] == 0
     cols0 = np.repeat(np.arange(problem["rowptr"].shape[0] - 1), np.diff(problem["rowptr"]))[first]
@@ -129,9 +128,61 @@ def test_ties_and_duplicates(oracle):
     problem["q_cols"] = np.concatenate(q_cols).astype(np.int32)
     idf64 = problem["idf32"].astype(np.float64)
     problem["q_maxint"] = np.array([float(np.sum(idf64[c])) for c in q_cols])
-    index = _check(oracle, problem, 10)
+    return problem
+
+
+@pytest.mark.parametrize("k", [1, 10, 100])
+def test_ties_and_duplicates(oracle, k):
+    """6000 identical truth rows (same columns, same sums32): the fast kernel keeps the k twins of largest row index
+    (match_maker.py:71 returns the k largest indexes) and serves the tie queries itself, bit-exactly."""
+    problem = _tie_problem(np.random.RandomState(5), 50000, 6000)
+    index = _check(oracle, problem, k)
     stats = index.sync()
-    assert stats["dense_queries"] >= 1  # the tie-heavy queries must have used the exact dense kernel
+    assert stats["dense_reasons"]["ties"] == 0 and stats["dense_reasons"]["overflow_sparse"] == 0
+    assert stats["dense_reasons"]["overflow_dense"] == 0 and stats["error_queries"] == 0
+
+
+def test_twins_with_different_sums_are_different_classes(oracle):
+    """Twin rows (same columns) whose sums32 differ are NOT interchangeable: their jaccard differs.  Half of the 6000
+    twins get the next float32 up; both classes are long, rows of both can be among the answers."""
+    problem = _tie_problem(np.random.RandomState(6), 50000, 6000)
+    sums = problem["sums32"].copy()
+    odd = np.arange(1, 6000, 2)
+    sums[odd] = np.nextafter(sums[odd], np.float32(np.inf))
+    problem["sums32"] = sums
+    for k in (10, 100):
+        index = _check(oracle, problem, k)
+        assert index.sync()["dense_reasons"]["ties"] == 0
+
+
+def test_near_ties_that_are_not_twins_still_exact(oracle):
+    """Thousands of rows that tie without being twins (same matched columns, different other columns, equal sums32 by
+    construction): the rank rule does not apply; whatever path serves them, the answer equals the oracle's."""
+    rng = np.random.RandomState(8)
+    problem = _random_problem(rng, 60000, 2000, 8)
+    n_columns = problem["rowptr"].shape[0] - 1
+    # rows 0..3999 share columns {10, 11, 12}; each also owns one of two filler columns with equal idf
+    lists = [problem["truth_idx"][problem["rowptr"][g]:problem["rowptr"][g + 1]] for g in range(n_columns)]
+    tied = np.arange(4000, dtype=np.int32)
+    lists = [l[l >= 4000] for l in lists]
+    for g in (10, 11, 12):
+        lists[g] = np.concatenate((tied, lists[g]))
+    lists[20], lists[21] = tied[::2], tied[1::2]
+    problem["rowptr"] = np.concatenate(([0], np.cumsum([len(l) for l in lists]))).astype(np.int64)
+    problem["truth_idx"] = np.concatenate(lists).astype(np.int32)
+    idf32 = problem["idf32"].copy()
+    idf32[21] = idf32[20]
+    problem["idf32"] = idf32
+    sums = problem["sums32"].copy()
+    sums[:4000] = np.float32(idf32[10]) + np.float32(idf32[11]) + np.float32(idf32[12]) + np.float32(idf32[20])
+    problem["sums32"] = sums
+    q_cols = [np.array([10, 11, 12], dtype=np.int32)] * 4 + [np.array([10, 11, 12, 20], dtype=np.int32)] * 4
+    problem["q_rowptr"] = np.concatenate(([0], np.cumsum([len(c) for c in q_cols]))).astype(np.int64)
+    problem["q_cols"] = np.concatenate(q_cols).astype(np.int32)
+    idf64 = idf32.astype(np.float64)
+    problem["q_maxint"] = np.array([float(np.sum(idf64[c])) for c in q_cols])
+    for k in (10, 50):
+        _check(oracle, problem, k)
 
 
 def test_edge_cases(oracle):

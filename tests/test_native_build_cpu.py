@@ -70,3 +70,26 @@ def test_bad_arguments():
         ds.NativeProblem(["abc"], ["abc"], n_gram=4)
     with pytest.raises(ds.DoppelError):
         ds.NativeProblem([], ["abc"])
+
+
+def test_duplicate_ranks_against_a_dictionary():
+    """ds_index_duplicate_ranks (host part of ds_index_create): rank = twins (same column set, same sums32 bits) with
+    a larger row index.  Checked against a Python dictionary on a workload with many duplicated titles."""
+    import ctypes
+    from doppel_speller_amd import _lib, synth
+    w = synth.make_workload(40000, 10, seed=13)
+    sums = w.sums32.copy()
+    sums[::7] = np.nextafter(sums[::7], np.float32(np.inf))   # same columns, other sums: another class
+    ranks = np.full(w.n_truth, 9999, dtype=np.uint16)
+    _lib.check(_lib.lib().ds_index_duplicate_ranks(_lib.pointer(w.rowptr), _lib.pointer(w.truth_idx), _lib.pointer(sums),
+                                                   w.n_columns, w.n_truth, _lib.pointer(ranks)), "duplicate ranks")
+    columns = np.repeat(np.arange(w.n_columns), np.diff(w.rowptr))
+    order = np.argsort(w.truth_idx, kind="stable")
+    per_row = np.split(columns[order], np.cumsum(np.bincount(w.truth_idx, minlength=w.n_truth))[:-1])
+    seen, expected = {}, np.zeros(w.n_truth, dtype=np.uint16)
+    for t in range(w.n_truth - 1, -1, -1):
+        key = (per_row[t].tobytes(), sums[t].tobytes())
+        expected[t] = seen.get(key, 0)
+        seen[key] = expected[t] + 1
+    assert np.array_equal(ranks, expected)
+    assert expected.max() >= 10   # the workload does contain long runs of twins
