@@ -131,6 +131,33 @@ def _stage_example_data(directory):
             shutil.copyfileobj(source, target)
 
 
+def _set_order_ranks(n_gram_sets, encoding):
+    """The iteration order of every title's n-gram set (what `sum(uniqueness_values)` of match_maker.py:174 adds in),
+    stored compactly: for the i-th element of the iteration, its rank among the title's ascending column ids."""
+    ranks = []
+    for n_grams in n_gram_sets:
+        columns = [encoding[n_gram] for n_gram in n_grams]
+        position = {column: rank for rank, column in enumerate(sorted(columns))}
+        ranks.extend(position[column] for column in columns)
+    assert max(ranks) < 256
+    return np.array(ranks, dtype=np.uint8)
+
+
+def _match_maker_answers(match_maker, s, mm, q_maxint, n_query, top_n):
+    rows = np.zeros((n_query, top_n), dtype=np.int32)
+    margin_ok = np.zeros(n_query, dtype=bool)
+    for q in range(n_query):
+        jaccard = match_maker.fast_jaccard(
+            mm.number_of_truth_titles, float(q_maxint[q]), mm.matrix_non_zero_columns[q],
+            mm.matrix_truth_non_zero_columns_and_values, mm.sums_matrix_truth)
+        rows[q] = match_maker.fast_arg_top_k(jaccard, top_n)
+        positive = np.sort(jaccard[jaccard > 0])[::-1]
+        kth = np.float32(positive[top_n - 1]) if positive.shape[0] >= top_n else np.float32(0)
+        threshold = np.float64(kth) - np.float64(np.float32(s.ENCODING_FLOAT_BUFFER))
+        margin_ok[q] = np.abs(jaccard - threshold).min() > 5e-7
+    return rows, margin_ok
+
+
 def main():
     data_dir = tempfile.mkdtemp(prefix="ds_golden_")
     _stage_example_data(data_dir)
@@ -237,6 +264,8 @@ def main():
             assert jac.dtype == np.float64
             fixture.update(jac_rows=np.array(jac_rows), jac=jac)
 
+        if top_n == 10:
+            fixture.update(truth_order_rank=_set_order_ranks(truth[c.COLUMN_N_GRAMS], mm.n_grams_encoding))
         rows = np.zeros((n_query, top_n), dtype=np.int32)
         ids = np.zeros((n_query, top_n), dtype=np.int64)
         margin_ok = np.zeros(n_query, dtype=bool)
@@ -288,6 +317,34 @@ def main():
         truth_enc=truth_enc, counts=counts, space_code=np.uint8(encoding[" "]), n_truth=n_truth_titles,
         features=features, titles=np.array([q_titles[q] for q in pair_q]),
         truth_titles=np.array([t_titles[t] for t in pair_t]))
+
+    # ------------------------------------------------------------------ D. MatchMaker on the WHOLE example truth set
+    # 30,000 truth rows = two score tiles of the HIP kernel (28,672 rows each): pointer-cache spans, sparse tiles and
+    # cross-tile MaxScore are exercised by vectors captured from the reference.  Stored: titles, the vocabulary order,
+    # each truth title's set iteration order, sums_matrix_truth, and the answers (rows) for k = 10 and k = 100.
+    n_query_full = 1000
+    truth_full = truth_all.reset_index(drop=True)
+    query_full = test_all.iloc[:n_query_full].reset_index(drop=True)
+    full = {}
+    for top_n in (10, 100):
+        mm = match_maker.MatchMaker(query_full.copy(), truth_full.copy(), top_n)
+        if top_n == 10:
+            q_maxint = np.array([sum([mm._get_idf_given_index(r) for r in mm.matrix_non_zero_columns[q]])
+                                 for q in range(n_query_full)], dtype=np.float64)
+            full.update(
+                truth_titles=np.array(list(truth_full[c.COLUMN_TRANSFORMED_TITLE])),
+                query_titles=np.array(list(query_full[c.COLUMN_TRANSFORMED_TITLE])),
+                vocab=np.array(sorted(mm.n_grams_encoding, key=mm.n_grams_encoding.get)),
+                title_id=np.asarray(truth_full[c.COLUMN_TITLE_ID], dtype=np.int32),
+                truth_order_rank=_set_order_ranks(truth_full[c.COLUMN_N_GRAMS], mm.n_grams_encoding),
+                sums32=mm.sums_matrix_truth.astype(np.float32), q_maxint=q_maxint)
+        rows, margin_ok = _match_maker_answers(match_maker, s, mm, full["q_maxint"], n_query_full, top_n)
+        for q in (0, 1, 500, 999):
+            assert mm.get_closest_matches(q) == full["title_id"][rows[q]].tolist()
+        full[f"rows_k{top_n}"] = rows
+        full[f"margin_ok_k{top_n}"] = margin_ok
+    np.savez_compressed(f"{HERE}/match_maker_30000x1000.npz", **full)
+    print("30000 x 1000 margin_ok k10/k100:", int(full["margin_ok_k10"].sum()), int(full["margin_ok_k100"].sum()))
 
     shutil.rmtree(data_dir)
     print("levenshtein KATs:", len(lev))

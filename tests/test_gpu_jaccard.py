@@ -225,26 +225,48 @@ def test_k_larger_than_truth_raises(oracle):
 
 
 def test_match_maker_drop_in(golden_match_maker):
-    """The reference's call surface on DataFrames, with the captured vocabulary order injected."""
-    import pandas as pd
+    """The reference's call surface on DataFrames.  The captured vocabulary order and every truth title's captured set
+    iteration order are injected, so every array and every answer is EXACTLY the reference's."""
     import doppel_speller_amd as ds
+    from conftest import golden_frames
     g = golden_match_maker
-    n_grams = lambda title: set(title[i:i + 3] for i in range(len(title)) if len(title[i:i + 3]) == 3)
-    truth = pd.DataFrame({"title_id": g["title_id"], "n_grams": [n_grams(str(t)) for t in g["truth_titles"]]})
-    data = pd.DataFrame({"n_grams": [n_grams(str(t)) for t in g["query_titles"]]})
-    mm = ds.MatchMaker(data, truth, 10, vocabulary=[str(v) for v in g["vocab"]])
+    data, truth, vocabulary = golden_frames(g)
+    mm = ds.MatchMaker(data, truth, 10, vocabulary=vocabulary)
     assert mm.top_n == 10 and mm.number_of_truth_titles == 5000 and not hasattr(mm, "data")
     assert list(mm.truth_data.columns) == ["title_id"]
     assert np.array_equal(mm.index.idf32, g["idf32"]) and np.array_equal(mm.index.rowptr, g["rowptr"])
     assert np.array_equal(mm.index.truth_idx, g["truth_idx"])
     assert np.array_equal(mm._q_cols, g["q_cols"]) and np.array_equal(mm._q_maxint, g["q_maxint"])
-    assert np.allclose(mm.sums_matrix_truth, g["sums32"], rtol=1e-6)  # set iteration order may differ (H6)
-    agree = 0
+    assert np.array_equal(mm.sums_matrix_truth.view(np.uint32), g["sums32"].view(np.uint32))
     for q in range(200):
         ids = mm.get_closest_matches(q)
         assert isinstance(ids, list) and len(ids) == 10
-        agree += ids == g["ids_k10"][q].tolist()
-    assert agree >= 198  # identical unless a set-order rounding difference in sums flips a near-tie
+        assert ids == g["ids_k10"][q].tolist()   # margin_ok is all true at k = 10
+
+
+def test_whole_example_truth_set(oracle, golden_match_maker_full):
+    """The reference MatchMaker's answers on its whole example truth set (30,000 rows: crosses the 28,672-row tile
+    boundary, so list-pointer spans, sparse tiles and MaxScore across tiles run on reference-captured vectors)."""
+    import doppel_speller_amd as ds
+    from conftest import golden_frames
+    g = golden_match_maker_full
+    index = ds.TruthIndex(g["rowptr"], g["truth_idx"], g["idf32"], g["sums32"])
+    assert index.info()["tiles"] == 2
+    for k in (10, 100):
+        got = index.top_k(g["q_rowptr"], g["q_cols"], g["q_maxint"], k)
+        ok = g[f"margin_ok_k{k}"]
+        assert np.array_equal(got[ok], g[f"rows_k{k}"][ok])                     # captured from the reference
+        expected = oracle.jaccard_topk(g["rowptr"], g["truth_idx"], g["idf32"], g["sums32"], g["q_rowptr"],
+                                       g["q_cols"], g["q_maxint"], k)
+        assert np.array_equal(got, expected)                                     # every vector, specification typing
+    stats = index.sync()
+    assert stats["error_queries"] == 0 and stats["dense_queries"] <= 10        # served by the fast kernel
+    # the drop-in surface on the same data: ids, not rows
+    data, truth, vocabulary = golden_frames(g)
+    mm = ds.MatchMaker(data, truth, 100, vocabulary=vocabulary)
+    ok = g["margin_ok_k100"]
+    for q in np.nonzero(ok)[0][::10]:
+        assert mm.get_closest_matches(int(q)) == g["title_id"][g["rows_k100"][q]].tolist()
 
 
 def test_match_maker_from_titles_equals_dataframe_build():

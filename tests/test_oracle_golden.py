@@ -1,5 +1,7 @@
 """The CPU oracle (oracle/doppel_oracle.c) against the golden vectors captured from the reference's own function
 bodies (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 
 
@@ -98,3 +100,22 @@ def test_construct_features_survey_example(oracle, golden_kat):
     assert out[21:25].tolist() == [6, 12, 2, 2]
     assert np.allclose(out[36:40], [10.309, 4.5854, 6.3771, 1.8073], atol=1e-4)
     assert np.allclose(out[51:55], [1, 2.4309, 1.983, 3.1254], atol=1e-4)
+
+
+def test_whole_example_truth_set(oracle, golden_match_maker_full):
+    """30,000 truth rows x 1,000 queries captured from the reference MatchMaker (k = 10 and 100): the host-side index
+    build reproduces sums_matrix_truth / max_intersection_possible bit for bit and the oracle reproduces the answers."""
+    g = golden_match_maker_full
+    assert g["sums32"].shape[0] == 30000
+    fixture = np.load(os.path.join(os.path.dirname(__file__), "golden", "match_maker_30000x1000.npz"))
+    assert np.array_equal(g["sums32"].view(np.uint32), fixture["sums32"].view(np.uint32))
+    assert np.array_equal(g["q_maxint"].view(np.uint64), fixture["q_maxint"].view(np.uint64))
+    for k in (10, 100):
+        numpy_typed = oracle.jaccard_topk(g["rowptr"], g["truth_idx"], g["idf32"], g["sums32"], g["q_rowptr"],
+                                          g["q_cols"], g["q_maxint"], k, "numpy")
+        assert np.array_equal(numpy_typed, g[f"rows_k{k}"])
+        numba_typed = oracle.jaccard_topk(g["rowptr"], g["truth_idx"], g["idf32"], g["sums32"], g["q_rowptr"],
+                                          g["q_cols"], g["q_maxint"], k, "numba")
+        ok = g[f"margin_ok_k{k}"]
+        assert ok.sum() >= 0.99 * ok.shape[0]
+        assert np.array_equal(numba_typed[ok], g[f"rows_k{k}"][ok])
