@@ -3,26 +3,39 @@
 
 A step = one pass of the hot path over one batch of synthetic queries that is already resident in HBM:
 Jaccard top-k of every query against the whole truth index, then construct_features on the Q*k surviving pairs
-(metric of BASELINE.json: Q*k / (t_jaccard+topk + t_features)).  Default workload = BASELINE.json configs[1]
-(100k queries x 500k truth titles, top-10) on one GPU.
+(metric of BASELINE.json: Q*k / (t_jaccard+topk + t_features)).
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py                                   # C2 on one GPU (BASELINE.json configs[1], the metric's config)
+    python bench.py --config C3                       # 1M queries x 5M truth titles, top-50
+    python bench.py --gpus 8 --config C4              # spawns 8 fresh rank processes itself (one per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W        # the driver's launcher: RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* are read
 
-With N > 1 every rank (one process per GPU) owns its own shard of `--queries` queries (weak scaling: the per-GPU batch
-is fixed), the truth index is replicated, and each step ends with the single all-gather of the int32 top-k rows over
-RCCL.  Rank 0 prints ONE JSON line.  torch is only imported for N > 1 (rendezvous, barrier, RCCL).
+Configurations (BASELINE.json `configs`; per-GPU batch given, truth replicated on every GPU):
+    C2  100k queries per GPU x 500k truth titles, top-10            (weak scaling with --gpus N)
+    C3  1M queries per GPU x 5M truth titles, top-50                 (weak)
+    C4  8M queries in all, sharded by query (1M per GPU at 8 GPUs) x 5M truth titles, top-50     (strong)
+    C5  1M queries in all (125k per GPU at 8 GPUs) x 50M truth titles, top-100 + all features     (strong)
+
+With N > 1 every rank (one process per GPU) owns its shard of the queries, the truth index is replicated, and each
+step ends with the single all-gather of the int32 top-k rows over RCCL (ctypes binding, no PyTorch); barriers and
+the max over ranks go through a TCP rendezvous.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      Jaccard kernel: ALGORITHMIC bytes (4*sum|P_g| + 4N + 16|G_q| + 4k per query) / average
-                duration of the Jaccard launch measured with HIP events on the launch stream, against 8 TB/s.
-  cpu_baseline  the oracle (C restatement of the reference, OpenMP over all host cores) timed on a bounded sample of
-                the same workload (rank 0, N=1 only).
+  roofline      ds_jaccard_topk_kernel against the HBM roofline: achieved = bytes the kernel REQUESTS from global
+                memory per launch (counted by the kernel: postings, per-posting info, sums32, signatures, list
+                pointers, exact-stage probes) / its average launch duration (HIP events on the launch stream);
+                `traffic` = FETCH_SIZE + WRITE_SIZE of profiles/pmc_latest.json when that file was measured on this
+                build and workload; `bound_model` = the kernel's shares of VALU issue, LDS and HBM time from the same
+                counters; `speedup_over_reference_hbm_floor` = the bytes the REFERENCE's algorithm would read
+                 / launch duration / 8 TB/s -- above 1 because the kernel skips most of them.
+  cpu_baseline  the oracle (C restatement of the reference, OpenMP) timed on a bounded sample of the same workload
+                (rank 0, N=1 only), best of a thread sweep.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,21 +45,41 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS = 256 * 4           # 256 CUs x 4 SIMD-32: one VALU wave-instruction issues over 2 cycles (same guide)
+CONFIGS = {
+    # name: (queries, "per_gpu" | "total", truth titles, k, text of BASELINE.json's config)
+    "C2": (100_000, "per_gpu", 500_000, 10, "100k synthetic queries x 500k truth titles, tri-gram vocab ~50k, top-10"),
+    "C3": (1_000_000, "per_gpu", 5_000_000, 50, "1M queries x 5M truth titles, top-50"),
+    "C4": (8_000_000, "total", 5_000_000, 50, "8M queries x 5M truth titles sharded by query, RCCL gather of top-k"),
+    "C5": (1_000_000, "total", 50_000_000, 100, "1M queries x 50M truth titles, truth replicated per GPU, top-100 + "
+                                               "full Levenshtein feature vector"),
+}
 
 
 def log(*args):
     print(*args, file=sys.stderr, flush=True)
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as handle:
+            for line in handle:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(workload, k, budget_seconds):
-    """Oracle on the host cores, bounded sample: returns the dict for the JSON line."""
+    """Oracle on the host cores, bounded sample, best thread count of a sweep: the dict for the JSON line."""
     from oracle import oracle
     oracle.build()
     cores = oracle.num_threads()
-    pilot = min(workload.n_queries, max(2 * cores, 16))
 
-    def run(n_sample):
+    def run(n_sample, threads):
+        oracle.set_num_threads(threads)
         first, last = int(workload.q_rowptr[0]), int(workload.q_rowptr[n_sample])
         t0 = time.perf_counter()
         rows = oracle.jaccard_topk(workload.rowptr, workload.truth_idx, workload.idf32, workload.sums32,
@@ -60,14 +93,42 @@ def cpu_baseline(workload, k, budget_seconds):
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1
 
-    tj, tf = run(pilot)
-    per_query = (tj + tf) / pilot
-    n_sample = int(min(workload.n_queries, max(pilot, budget_seconds / max(per_query, 1e-9))))
-    tj, tf = run(n_sample)
-    return {"value": n_sample * k / (tj + tf), "unit": "candidate-pairs/s", "cores": cores, "kind": "port",
+    # thread sweep on small pilots (the per-thread N-vectors of the reference's algorithm thrash the caches when every
+    # hardware thread runs one): 1 thread, then 32 / 64 / ... / all
+    sweep = {}
+    candidates = sorted({1, cores} | {t for t in (8, 16, 32, 64, 128) if t < cores})
+    for threads in candidates:
+        pilot = min(workload.n_queries, max(2 * threads, 8))
+        tj, tf = run(pilot, threads)
+        sweep[threads] = pilot * k / (tj + tf)
+        if tj + tf > budget_seconds / 3:
+            break
+    best = max(sweep, key=sweep.get)
+    n_sample = int(min(workload.n_queries, max(2 * best, 0.5 * budget_seconds * sweep[best] / k)))
+    tj, tf = run(n_sample, best)
+    oracle.set_num_threads(cores)
+    return {"value": n_sample * k / (tj + tf), "unit": "candidate-pairs/s", "cores": best, "kind": "port",
             "sample": f"first {n_sample} queries of the workload x {workload.n_truth} truth titles, top-{k} "
-                      f"(jaccard+topk {tj:.2f}s, features {tf:.2f}s on {cores} OpenMP threads)",
+                      f"(jaccard+topk {tj:.2f}s, features {tf:.2f}s on {best} OpenMP threads)",
+            "cpu": cpu_model(), "host_threads": cores,
+            "thread_sweep_pairs_per_s": {str(t): round(v, 1) for t, v in sweep.items()},
             "queries_per_s": n_sample / tj, "feature_pairs_per_s": n_sample * k / tf}
+
+
+def spawn_ranks(gpus):
+    """`--gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE this process touches the GPU and
+    exit with their worst status.  Rank 0 inherits stdout (the JSON line); the other ranks' stdout goes to stderr."""
+    import socket
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    ranks = []
+    for rank in range(gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        ranks.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if rank == 0 else sys.stderr))
+    return max(process.wait() for process in ranks)
 
 
 def main():
@@ -75,58 +136,69 @@ def main():
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=3)
     parser.add_argument("--warmup", type=int, default=1)
-    parser.add_argument("--queries", type=int, default=100000, help="queries per GPU")
-    parser.add_argument("--truth", type=int, default=500000)
-    parser.add_argument("--k", type=int, default=10)
+    parser.add_argument("--config", choices=sorted(CONFIGS), default="C2")
+    parser.add_argument("--queries", type=int, default=None, help="queries per GPU (overrides the configuration)")
+    parser.add_argument("--truth", type=int, default=None)
+    parser.add_argument("--k", type=int, default=None)
     parser.add_argument("--seed", type=int, default=20260101)
     parser.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget (0 disables)")
     parser.add_argument("--check", type=int, default=64, help="queries verified against the oracle after the run")
+    parser.add_argument("--host-communicator", action="store_true",
+                        help="gather through the TCP rendezvous instead of RCCL (rehearsals without N GPUs)")
     args = parser.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
-    # DS_BENCH_FORCE_DIST=1 exercises the torch.distributed / RCCL plumbing with a single rank (1-GPU rehearsal)
+        log(f"error: --gpus {args.gpus} but WORLD_SIZE={world}")
+        sys.exit(2)
+
+    queries, mode, truth, k, text = CONFIGS[args.config]
+    per_gpu = queries if mode == "per_gpu" else queries // world
+    scaling = "weak" if mode == "per_gpu" else "strong"
+    custom = args.queries is not None or args.truth is not None or args.k is not None
+    if args.queries is not None:
+        per_gpu, scaling = args.queries, "weak"
+    truth = args.truth if args.truth is not None else truth
+    k = args.k if args.k is not None else k
+    # DS_BENCH_FORCE_DIST=1 exercises the rendezvous / RCCL plumbing with a single rank (1-GPU rehearsal)
     distributed = world > 1 or os.environ.get("DS_BENCH_FORCE_DIST") == "1"
 
     import doppel_speller_amd as ds
     from doppel_speller_amd import _lib, synth
-    from doppel_speller_amd.distributed import gather_rows
+    from doppel_speller_amd.distributed import HostCommunicator, RcclCommunicator, Rendezvous, RowGather
 
-    torch = None
-    rows_tensor = None
+    device = 0 if os.environ.get("DS_BENCH_SAME_DEVICE") == "1" else local_rank   # rehearsals on a one-GPU box
+    rendezvous = communicator = gather = None
     if distributed:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        rendezvous = Rendezvous.from_environment()
+        communicator = HostCommunicator(rendezvous) if args.host_communicator else RcclCommunicator(rendezvous, device)
 
     # ---- synthetic workload: truth replicated (same seed), queries distinct per rank
     t0 = time.perf_counter()
-    workload = synth.make_workload(args.truth, args.queries, seed=args.seed, query_seed=args.seed + 1000 * (rank + 1))
+    workload = synth.make_workload(truth, per_gpu, seed=args.seed, query_seed=args.seed + 1000 * (rank + 1))
     if rank == 0:
         log(f"workload: {time.perf_counter() - t0:.1f}s  {synth.workload_statistics(workload)}")
-    device = local_rank
-    rows_ptr = None
-    if distributed:
-        rows_tensor = torch.empty((args.queries, args.k), dtype=torch.int32, device=f"cuda:{local_rank}")
-        rows_ptr = rows_tensor.data_ptr()
     t0 = time.perf_counter()
-    pipeline = ds.CandidatePipeline(workload, args.k, device=device, rows_ptr=rows_ptr)
+    pipeline = ds.CandidatePipeline(workload, k, device=device)
     if rank == 0:
         log(f"upload + index build: {time.perf_counter() - t0:.1f}s  {pipeline.index.info()}")
-    stream = torch.cuda.current_stream().cuda_stream if distributed else 0
+    stream_handle = None
+    stream = 0
+    if distributed:
+        import ctypes
+        stream_handle = ctypes.c_void_p()
+        _lib.check(_lib.lib().ds_stream_create(device, ctypes.byref(stream_handle)), "ds_stream_create")
+        stream = stream_handle.value
+        gather = RowGather(communicator, per_gpu * world, k, device)
 
     def barrier():
+        _lib.check(_lib.lib().ds_stream_sync(stream_handle, device), "sync")
         if distributed:
-            torch.distributed.barrier()
-            torch.cuda.synchronize()
-        else:
-            _lib.check(_lib.lib().ds_stream_sync(None, device), "sync")
+            rendezvous.barrier()
 
     timer_j, timer_f = _lib.Timer(device), _lib.Timer(device)
     jaccard_ms, feature_ms, topk_kernel_ms, dense_kernel_ms = [], [], [], []
@@ -141,9 +213,12 @@ def main():
         pipeline.enqueue_features(stream)
         timer_f.stop(stream)
         if os.environ.get("DS_BENCH_SYNC_EACH") == "1":
-            _lib.check(_lib.lib().ds_stream_sync(None, device), "sync"); log("features done")
+            _lib.check(_lib.lib().ds_stream_sync(stream_handle, device), "sync"); log("features done")
         if distributed:
-            gather_rows(rows_tensor, args.queries * world)
+            if communicator.on_device:
+                gather.gather(pipeline.rows_ptr, stream)          # ONE ncclAllGather on the same stream
+            else:
+                gather.gather(pipeline.rows())
         if record:
             jaccard_ms.append(timer_j.elapsed_ms())   # synchronises on the stop events
             feature_ms.append(timer_f.elapsed_ms())
@@ -160,13 +235,15 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_begin
     stats = pipeline.sync(stream)
-
     if distributed:
-        worst = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        torch.distributed.all_reduce(worst, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(worst.item())
+        elapsed = rendezvous.max(elapsed)
+    # one more launch, untimed, with the instantiation of the kernel that counts the bytes it requests (same work)
+    pipeline.index.option("count_bytes", 1)
+    pipeline.enqueue_top_k(stream)
+    stats["requested_bytes"] = pipeline.sync(stream)["requested_bytes"]
+    pipeline.index.option("count_bytes", 0)
 
-    # ---- next row f-1 on the same resident data, timed on its own (not part of the metric)
+    # ---- next rows on the same resident data, timed on their own (not part of the metric)
     next_rows = {}
     if not distributed:
         timer_c = _lib.Timer(device)
@@ -175,7 +252,7 @@ def main():
         pipeline.enqueue_close_matches(stream)
         timer_c.stop(stream)
         next_rows["close_matches_ms"] = timer_c.elapsed_ms()
-        next_rows["close_match_pairs_per_s"] = args.queries * args.k / (next_rows["close_matches_ms"] * 1e-3)
+        next_rows["close_match_pairs_per_s"] = per_gpu * k / (next_rows["close_matches_ms"] * 1e-3)
         from doppel_speller_amd import ForestModel
         f = synth.make_forest()                              # 300 random trees of depth 6 (the model file is not in the tree)
         model = ForestModel(f["feature"], f["threshold"], f["yes"], f["no"], f["missing"], f["tree_offsets"],
@@ -192,15 +269,15 @@ def main():
     cells_per_pair = None
     if args.check > 0:
         from oracle import oracle
-        n_check = min(args.check, args.queries)
+        n_check = min(args.check, per_gpu)
         rows = pipeline.rows()[:n_check]
         last = int(workload.q_rowptr[n_check])
         expected = oracle.jaccard_topk(workload.rowptr, workload.truth_idx, workload.idf32, workload.sums32,
                                        workload.q_rowptr[:n_check + 1], workload.q_cols[:last],
-                                       workload.q_maxint[:n_check], args.k)
+                                       workload.q_maxint[:n_check], k)
         assert np.array_equal(rows, expected), "top-k rows differ from the oracle"
-        features = pipeline.features()[:n_check * args.k]
-        pair_q = np.repeat(np.arange(n_check), args.k)
+        features = pipeline.features(n_check * k)
+        pair_q = np.repeat(np.arange(n_check), k)
         pair_t = rows.reshape(-1)
         reference = oracle.construct_features(workload.q_len[pair_q], workload.t_len[pair_t], workload.q_enc[pair_q],
                                               workload.t_enc[pair_t], workload.t_counts[pair_t], 1, workload.n_truth)
@@ -211,59 +288,75 @@ def main():
                                                             workload.q_enc[pair_q], workload.t_enc[pair_t], 1)))
 
     if rank == 0:
-        pairs_per_step = args.queries * args.k * world
+        pairs_per_step = per_gpu * k * world
         ms_per_step = 1000.0 * elapsed / args.steps
-        bytes_jaccard = synth.algorithmic_bytes_jaccard(workload, args.k)
+        reference_bytes = synth.algorithmic_bytes_jaccard(workload, k)
         mean_j = float(np.mean(jaccard_ms))
         mean_topk = float(np.mean(topk_kernel_ms))   # ds_jaccard_topk_kernel alone (the dominant kernel)
-        achieved = bytes_jaccard / (mean_topk * 1e-3) / 1e9
-        traffic = None
+        requested = int(stats["requested_bytes"])     # bytes the kernel asked global memory for, last launch
+        achieved = requested / (mean_topk * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "ds_jaccard_topk_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": requested, "avg_launch_ms": mean_topk,
+                    "bytes_per_query": requested / max(1, per_gpu),
+                    "note": "algorithmic bytes = what THIS kernel requests from global memory per launch (2-byte "
+                            "postings of the traversed lists + per-posting info, sums32, signatures, list pointers, "
+                            "exact-stage probes), counted by the kernel; `traffic` = PMC FETCH_SIZE + WRITE_SIZE"}
         pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as handle:
                 pmc = json.load(handle)
-            if pmc.get("queries") == args.queries and pmc.get("truth") == args.truth and pmc.get("k") == args.k:
-                traffic = pmc.get("hbm_bytes_per_launch")
+            same = (pmc.get("queries") == per_gpu and pmc.get("truth") == truth and pmc.get("k") == k and
+                    pmc.get("build_id") == _lib.lib().ds_build_id().decode())
+            if same:  # counters of THIS build on THIS workload (scripts/profile_pmc.sh); stale files are ignored
+                roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
+                roofline["bound_model"] = pmc.get("bound_model")
         line = {
             "metric": "candidate-pairs scored/sec (Jaccard top-k + Levenshtein), 100k x 500k titles",
             "value": pairs_per_step / (elapsed / args.steps),
             "unit": "candidate-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32 accumulate / f64 finalise (Jaccard), u8 + f64 ratio (Levenshtein)",
             "data": "synthetic",
-            "config": {"workload": f"1xMI355X: {args.queries} synthetic queries x {args.truth} truth titles, "
-                                   f"tri-gram vocab {workload.n_columns}, top-{args.k}"
-                       if world == 1 else
-                       f"{world}xMI355X: {args.queries} queries per GPU x {args.truth} truth titles (replicated), "
-                       f"top-{args.k}, all-gather of rows",
-                       "queries_per_gpu": args.queries, "truth_titles": args.truth, "k": args.k,
+            "config": {"workload": (f"{args.config}: " if not custom else "custom: ") +
+                                   (f"{world}xMI355X: " + (text if not custom else "") +
+                                    f" [{per_gpu} queries per GPU x {truth} truth titles (replicated), tri-gram vocab "
+                                    f"{workload.n_columns}, top-{k}" +
+                                    (", one RCCL all-gather of the rows per step]" if world > 1 else "]")),
+                       "name": args.config if not custom else "custom",
+                       "queries_per_gpu": per_gpu, "truth_titles": truth, "k": k,
                        "seed": args.seed, "parallelism": f"query-shard x{world}"},
             "stages_ms": {"jaccard_topk": mean_j, "construct_features": float(np.mean(feature_ms)),
                           "ds_jaccard_topk_kernel": mean_topk,
                           "ds_jaccard_dense_kernel": float(np.mean(dense_kernel_ms))},
-            "queries_per_s": args.queries * world / (elapsed / args.steps),
+            "queries_per_s": per_gpu * world / (elapsed / args.steps),
             "per_stage": {
-                "jaccard_queries_per_s": args.queries / (mean_j * 1e-3),
-                "jaccard_postings_per_s": (bytes_jaccard - args.queries * (4 * args.truth + 4 * args.k)
+                "jaccard_queries_per_s": per_gpu / (mean_j * 1e-3),
+                "jaccard_postings_per_s": (reference_bytes - per_gpu * (4 * truth + 4 * k)
                                            - 16 * int(workload.q_rowptr[-1])) / 4 / (mean_j * 1e-3),
-                "feature_pairs_per_s": args.queries * args.k / (float(np.mean(feature_ms)) * 1e-3),
+                "feature_pairs_per_s": per_gpu * k / (float(np.mean(feature_ms)) * 1e-3),
                 "feature_reference_dp_cells_per_s": None if cells_per_pair is None else
-                    cells_per_pair * args.queries * args.k / (float(np.mean(feature_ms)) * 1e-3),
+                    cells_per_pair * per_gpu * k / (float(np.mean(feature_ms)) * 1e-3),
                 "reference_dp_cells_per_pair": cells_per_pair},
             "dense_path_queries": int(stats["dense_queries"]), "exact_candidates_per_query":
-                stats["exact_candidates"] / max(1, args.queries),
-            "verified_queries": checked, "selections_per_query": stats["selections"] / max(1, args.queries),
+                stats["exact_candidates"] / max(1, per_gpu),
+            "verified_queries": checked, "selections_per_query": stats["selections"] / max(1, per_gpu),
             "dense_reasons": stats["dense_reasons"],
             "tiles": {"sparse": stats["sparse_tiles"], "dense": stats["dense_tiles"]},
-            "skipped_columns_per_query": stats["skipped_columns"] / max(1, args.queries),
-            "roofline": {"bound": "hbm", "kernel": "ds_jaccard_topk_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_jaccard, "avg_launch_ms": mean_topk,
-                         "note": "algorithmic bytes = what the reference's algorithm reads (SURVEY 8d); the kernel "
-                                 "prunes most of it (MaxScore skipping, 2-byte postings), so achieved can exceed the "
-                                 "HBM peak; `traffic` is the measured FETCH_SIZE + WRITE_SIZE per launch"},
+            "skipped_columns_per_query": stats["skipped_columns"] / max(1, per_gpu),
+            "roofline": roofline,
+            # SURVEY.md 8d's figure: what the REFERENCE's algorithm reads (4-byte postings of every query column, 4 N
+            # bytes of sums per query ...).  The kernel skips most of it, hence a quotient above the HBM peak: this is
+            # a speed-up over the reference algorithm's bandwidth floor, not an efficiency.
+            "reference_algorithmic_bytes_per_launch": reference_bytes,
+            "speedup_over_reference_hbm_floor": reference_bytes / (mean_topk * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "build_id": _lib.lib().ds_build_id().decode(),
         }
+        if distributed:
+            line["rccl_ranks"] = world if communicator.on_device else 0
+            line["collective"] = "ncclAllGather int32[queries_per_gpu, k] per step" if communicator.on_device else \
+                "host all-gather through the TCP rendezvous (rehearsal)"
         if next_rows:
             line["next_rows"] = next_rows
         if any(stats["phase_cycles"].values()):  # library built with -DDS_DIAGNOSTICS and DS_PHASE_TIMERS=1
@@ -271,11 +364,12 @@ def main():
                                    "raw_entries_sparse": stats["raw_entries_sparse"],
                                    "bounds_record": stats.get("bounds_record")}
         if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(workload, args.k, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(workload, k, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if distributed:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        rendezvous.barrier()
+        communicator.close()
+        rendezvous.close()
 
 
 if __name__ == "__main__":

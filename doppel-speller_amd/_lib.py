@@ -78,6 +78,7 @@ def _declare(handle):
         "ds_index_create": [p, p, p, p, c.c_int64, c.c_int64, c.c_int, c.POINTER(p)],
         "ds_index_info": [p, c.POINTER(c.c_int64)],
         "ds_index_duplicate_ranks": [p, p, p, c.c_int64, c.c_int64, p],
+        "ds_index_option": [p, c.c_char_p, c.c_int64],
         "ds_jaccard_topk": [p, p, p, p, c.c_int64, c.c_int32, p],
         "ds_jaccard_topk_device": [p, p, p, p, c.c_int64, c.c_int32, p, p],
         "ds_jaccard_sync": [p, p, c.POINTER(c.c_int64)],
@@ -102,6 +103,9 @@ def _declare(handle):
         "ds_memcpy_d2h": [p, p, c.c_size_t, c.c_int],
         "ds_memset": [p, c.c_int, c.c_size_t, c.c_int],
         "ds_stream_sync": [p, c.c_int],
+        "ds_memcpy_d2d_async": [p, p, c.c_size_t, c.c_int, p],
+        "ds_stream_create": [c.c_int, c.POINTER(p)],
+        "ds_stream_destroy": [p, c.c_int],
         "ds_timer_create": [c.c_int, c.POINTER(p)],
         "ds_timer_start": [p, p],
         "ds_timer_stop": [p, p],
@@ -120,13 +124,13 @@ def _declare(handle):
 
 EXPORTED_SYMBOLS = (
     "ds_last_error", "ds_version", "ds_build_id", "ds_device_count", "ds_device_name", "ds_index_create", "ds_index_destroy",
-    "ds_index_duplicate_ranks",
+    "ds_index_duplicate_ranks", "ds_index_option",
     "ds_index_info", "ds_jaccard_topk", "ds_jaccard_topk_device", "ds_jaccard_sync", "ds_construct_features",
     "ds_titles_create", "ds_titles_destroy", "ds_construct_features_indexed", "ds_construct_features_indexed_device",
     "ds_levenshtein_ratio_batch", "ds_close_matches", "ds_close_matches_device", "ds_problem_create",
     "ds_problem_destroy", "ds_problem_info", "ds_problem_arrays", "ds_transform_titles", "ds_forest_create", "ds_forest_destroy",
     "ds_forest_predict", "ds_forest_predict_device", "ds_malloc", "ds_free", "ds_memcpy_h2d", "ds_memcpy_d2h", "ds_memset",
-    "ds_stream_sync", "ds_timer_create", "ds_timer_destroy", "ds_timer_start", "ds_timer_stop",
+    "ds_stream_sync", "ds_memcpy_d2d_async", "ds_stream_create", "ds_stream_destroy", "ds_timer_create", "ds_timer_destroy", "ds_timer_start", "ds_timer_stop",
     "ds_timer_elapsed_ms")
 
 
@@ -194,6 +198,19 @@ class DeviceArray:
         self.ptr = raw
 
     @classmethod
+    def view(cls, pointer, shape, dtype, device=0):
+        """A typed view of device memory owned by somebody else (never freed here)."""
+        import numpy as np
+        out = cls.__new__(cls)
+        out.shape = tuple(shape)
+        out.dtype = np.dtype(dtype)
+        out.device = device
+        out.nbytes = int(np.prod(out.shape, dtype=np.int64)) * out.dtype.itemsize
+        out.ptr = pointer if isinstance(pointer, ctypes.c_void_p) else ctypes.c_void_p(int(pointer))
+        out.owned = False
+        return out
+
+    @classmethod
     def from_host(cls, array, device=0):
         import numpy as np
         array = np.ascontiguousarray(array)
@@ -208,7 +225,7 @@ class DeviceArray:
         return out
 
     def free(self):
-        if self.ptr is not None and self.ptr.value:
+        if getattr(self, "owned", True) and self.ptr is not None and self.ptr.value:
             lib().ds_free(self.ptr, self.device)
             self.ptr = None
 

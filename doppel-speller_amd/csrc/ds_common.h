@@ -149,6 +149,7 @@ struct ds_index {
     int slow_slots = 16;
     hipEvent_t event_begin = nullptr, event_fast = nullptr, event_dense = nullptr;  // per-kernel timing of the last call
     bool attributes_set = false;
+    bool count_bytes = false;              // launch the instantiation of the fast kernel that counts its requested bytes
     int64_t last_queries = 0;
 };
 

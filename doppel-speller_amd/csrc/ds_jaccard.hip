@@ -70,7 +70,8 @@ struct JaccardArgs {
 // control words in HBM
 enum { kCtlQueue = 0, kCtlSlowCount = 1, kCtlErrors = 2, kCtlExact = 3, kCtlSelects = 4, kCtlSlowQueue = 5,
        kCtlSparseTiles = 6, kCtlDenseTiles = 7, kCtlSkippedColumns = 8, kCtlReason = 9 /* 9..14 */,
-       kCtlRefines = 16, kCtlRawEntries = 17, kCtlSurvivors = 18, kCtlRawSparse = 19 };
+       kCtlRefines = 16, kCtlRawEntries = 17, kCtlSurvivors = 18, kCtlRawSparse = 19,
+       kCtlBytes = 28 /* 28..29: uint64, bytes the fast kernel requested from global memory (all queries) */ };
 
 // LDS carve-up of the fast kernel (bytes)
 constexpr int kScoreWords = kTile / 2 + 16;  // two 16-bit scores per word + the trash word of the padding entries
@@ -110,8 +111,9 @@ constexpr int kProbeMaxK = kThreads / 4;  // threshold bootstrap from per-thread
 // LDS control words
 enum { kLQuery = 0, kLCount, kLOverflow, kLDigit, kLRemain, kLCoef, kLPre, kLCut, kLKth0, kLKth1, kLBad, kLItems,
        kLQuads, kLNonEssential, kLMass, kLSparse, kLSigMask /* 4 words */, kLQuant = kLSigMask + 4 /* quantisation error of the query's columns, 1/65536 units */, kLEnd,
-       kLStats = 24 /* 5 words: per-workgroup sums of the per-query statistics */ };
-static_assert(kLEnd <= kLStats && kLStats + 5 <= 32, "LDS control words");
+       kLStats = 24 /* 5 words: per-workgroup sums of the per-query statistics */,
+       kLBytes = 30 /* 30..31: uint64, bytes this workgroup requested from global memory */ };
+static_assert(kLEnd <= kLStats && kLStats + 5 <= kLBytes && kLBytes + 2 <= 32 && kLBytes % 2 == 0, "LDS control words");
 
 // Workgroup-uniform values read from LDS or computed on the vector ALU live in VGPRs unless the compiler is told that
 // they are uniform: `uniform` moves them to scalar registers (the kernel is VGPR-bound: 128 per lane at 2 WGs/CU).
@@ -318,6 +320,10 @@ __device__ __forceinline__ bool in_bounds(int32_t *control, int site, int64_t in
 #define DS_DEBUG_BIT(bit) false
 #endif
 
+// kCountBytes: the instantiation that also counts the bytes it requests from global memory (ds_index_option
+// "count_bytes"; bench.py runs it once, outside the timed region).  The counting costs 3 % in this register-bound
+// kernel, so the production instantiation carries none of it; both do exactly the same work on the same data.
+template <bool kCountBytes>
 __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void ds_jaccard_topk_kernel(JaccardArgs a)
 {
 #ifdef DS_DIAGNOSTICS
@@ -350,11 +356,25 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
     const int64_t ptr_stride = static_cast<int64_t>(a.n_tiles) + 1;
     const uint2 *quads = reinterpret_cast<const uint2 *>(a.postings);
     const uint2 *sums_quads = reinterpret_cast<const uint2 *>(a.posting_sums);
+    // The kernel arguments arrive as one 16-register tuple; under register pressure the allocator spills and reloads
+    // the WHOLE tuple (16 v_readlane in front of every posting load).  Opaque copies give the two pointers of the hot
+    // loops scalar register pairs of their own.
+    asm volatile("" : "+s"(quads));
+    asm volatile("" : "+s"(sums_quads));
 
     for (int i = tid * 4; i < kScoreWords; i += kThreads * 4)
         *reinterpret_cast<uint4 *>(&iscores[i]) = make_uint4(0u, 0u, 0u, 0u);
     if (tid < 5) ctrl[kLStats + tid] = 0;
+    if (tid < 2) ctrl[kLBytes + tid] = 0;
     __syncthreads();
+    // Global-memory bytes this workgroup REQUESTS (postings, per-posting info, sums32, signatures, list pointers, the
+    // exact stage's probes): the algorithmic traffic of this kernel, reported by bench.py next to the PMC counters.
+    unsigned long long *requested = reinterpret_cast<unsigned long long *>(lds + kOffCtrl + kLBytes * 4);
+    // Every term is workgroup-uniform: a query's total is summed in ONE scalar register, in units of 8 bytes, and thread 0
+    // adds it to its LDS word once per query (no atomics, nothing in the hot loops).  Not counted: the refinement's
+    // gathers (22 B per raw entry) and the exact stage's probes, together 1-2 % of the total.
+    uint32_t query_units = 0;
+    auto count_units = [&](uint32_t units) { if constexpr (kCountBytes) query_units += units; };
 
     for (;;) {
         if (tid == 0) {
@@ -388,6 +408,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             sig_bit[tid] = bit;
             if (bit >= 0) bit_idf[bit] = value;
         }
+        if constexpr (kCountBytes) query_units = static_cast<uint32_t>(17 * n + 24 + 7) >> 3;
         __syncthreads();
         if (uniform(static_cast<int>(ctrl[kLBad]))) {
             if (tid == 0) {
@@ -523,6 +544,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                                        ? a.col_ptr[static_cast<int64_t>(cols[j]) * ptr_stride + b + i]
                                        : 0u;
                 }
+                count_units(static_cast<uint32_t>(n * width + 1) >> 1);
                 __syncthreads();
             }
             const int bt = b - block_start;
@@ -608,6 +630,11 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 end = begin + quads_in_list;
                 value = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j < 64 ? fixed_lo : fixed_hi), l));
             };
+            if constexpr (kCountBytes) {  // posting bytes of this tile: 8 per quad and sweep, 8 more for the collect sweep's row info
+                const uint32_t scanned = wave_inclusive_scan(list_quads[0] + list_quads[1], lane);
+                const uint32_t tile_quads = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(scanned), 63));
+                count_units(tile_quads * (sparse ? (n_items <= DS_ROUND * kWaves ? 2u : 3u) : 1u));
+            }
             DS_STAMP(1);
 
             const int64_t tile_base = static_cast<int64_t>(b) * kTile;
@@ -664,6 +691,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 }
 #pragma unroll
                 for (int u = 0; u < kRound; ++u) {
+                    // exec-masked on purpose: unconditional atomics of idle lanes on trash words measured slower
+                    // (30.3 against 29.8 ms, profiles/r02_tuning.txt)
                     if (!live[u] || (sparse && DS_DEBUG_BIT(64))) continue;
                     add_packed(iscores, quad[u].x & 0xffffu, value[u]);
                     add_packed(iscores, quad[u].x >> 16, value[u]);
@@ -712,6 +741,18 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                             const uint32_t need = max(gate_fixed, static_cast<uint32_t>(need16[info[e] >> 8]));
                             pass[e] = (taken[e] != 0u) & (have >= need);
                         }
+#ifdef DS_DIAGNOSTICS
+                        if (a.phase != nullptr) {  // selectivity of a row-independent gate (tuning experiment)
+                            int touched = 0, level1 = 0;
+                            for (int e = 0; e < 4; ++e) {
+                                touched += taken[e] != 0u;
+                                level1 += taken[e] != 0u && taken[e] + mass16[255] >= gate_fixed;
+                            }
+                            for (int d = 32; d > 0; d >>= 1) { touched += __shfl_xor(touched, d); level1 += __shfl_xor(level1, d); }
+                            if (lane == 0) { atomicAdd(&a.control[20], touched); atomicAdd(&a.control[21], level1);
+                                             atomicAdd(&a.control[22], 1); atomicAdd(&a.control[23], level1 != 0); }
+                        }
+#endif
                         if (__ballot(pass[0] | pass[1] | pass[2] | pass[3]) == 0) continue;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) append_raw(pass[e], taken[e], local[e]);
@@ -796,6 +837,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                             }
                         }
                     }
+                    count_units(static_cast<uint32_t>(limit) >> 1);
                     uint32_t sample = 0u;
                     if (best_s > 0.f && !candidate_key(best_s, best_sums, bounds, sample)) sample = 0u;
                     cand_key[tid] = sample;
@@ -868,6 +910,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                         }
                     }
                     flush_raw();
+                    count_units(static_cast<uint32_t>(r1 - r0) >> 1);
                     __syncthreads();
                     DS_STAMP(3);
                     last_appended = uniform(static_cast<int>(ctrl[kLCount])) - count_at_step;
@@ -1130,6 +1173,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 ctrl[kLStats + 2] += sparse_tiles;
                 ctrl[kLStats + 3] += dense_tiles;
                 ctrl[kLStats + 4] += non_essential;
+                if constexpr (kCountBytes) *requested += 8ull * query_units;
             }
             __syncthreads();
             DS_STAMP(5);
@@ -1138,12 +1182,17 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 a.status[q] = kQuerySlow;
                 a.slow_list[atomicAdd(&a.control[kCtlSlowCount], 1)] = static_cast<int32_t>(q);
                 if (reason >= 0) atomicAdd(&a.control[kCtlReason + reason], 1);
+                if constexpr (kCountBytes) *requested += 8ull * query_units;
             }
             for (int i = tid * 4; i < kScoreWords; i += kThreads * 4)
                 *reinterpret_cast<uint4 *>(&iscores[i]) = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();
             DS_STAMP(0);
         }
+    }
+    if constexpr (kCountBytes) {
+        __syncthreads();
+        if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.control + kCtlBytes), *requested);
     }
     if (tid == 0) {
         atomicAdd(&a.control[kCtlExact], ctrl[kLStats + 0]);
@@ -1430,7 +1479,9 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
         if (status != DS_OK) return status;
     }
     if (!index->attributes_set) {
-        DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ds_jaccard_topk_kernel),
+        DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ds_jaccard_topk_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kFastLdsBytes));
+        DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ds_jaccard_topk_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kFastLdsBytes));
         DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ds_jaccard_dense_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kDenseLdsBytes));
@@ -1482,7 +1533,10 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     const int grid = static_cast<int>(std::min<int64_t>(Q, int64_t(index->compute_units) * kWorkgroupsPerCu));
     DS_HIP(hipMemsetAsync(index->control.ptr, 0, kControlWords * sizeof(int32_t), stream));
     DS_HIP(hipEventRecord(index->event_begin, stream));
-    hipLaunchKernelGGL(ds_jaccard_topk_kernel, dim3(grid), dim3(kThreads), kFastLdsBytes, stream, args);
+    if (index->count_bytes)
+        hipLaunchKernelGGL(ds_jaccard_topk_kernel<true>, dim3(grid), dim3(kThreads), kFastLdsBytes, stream, args);
+    else
+        hipLaunchKernelGGL(ds_jaccard_topk_kernel<false>, dim3(grid), dim3(kThreads), kFastLdsBytes, stream, args);
     DS_HIP(hipGetLastError());
     DS_HIP(hipEventRecord(index->event_fast, stream));
     hipLaunchKernelGGL(ds_jaccard_dense_kernel, dim3(index->slow_slots), dim3(kDenseThreads), kDenseLdsBytes, stream, args);
@@ -1519,7 +1573,7 @@ static int collect(ds_index *index, hipStream_t stream, int64_t stats[32])
         stats[12] = control[kCtlSparseTiles];
         stats[13] = control[kCtlDenseTiles];
         stats[14] = control[kCtlSkippedColumns];
-        stats[15] = 0;
+        std::memcpy(&stats[15], &control[kCtlBytes], sizeof(int64_t));  // bytes requested by the fast kernel
         for (int i = 0; i < 6; ++i) stats[16 + i] = control[kCtlReason + i];
         stats[22] = control[kCtlRefines];
         stats[23] = control[kCtlRawEntries];
@@ -1534,6 +1588,9 @@ static int collect(ds_index *index, hipStream_t stream, int64_t stats[32])
             stats[26] = stats[27] = 0;
         }
         for (int i = 28; i < 32; ++i) stats[i] = control[24 + (i - 28)];  // bounds-check record of debug builds
+        if (getenv("DS_PHASE_DUMP") != nullptr)
+            fprintf(stderr, "collect experiment: touched rows %d level-1 rows %d wave-quads %d wave-quads with level-1 %d\n",
+                    control[20], control[21], control[22], control[23]);
     }
     if (control[kCtlErrors] != 0 && index->last_queries > 0) {
         std::vector<int32_t> status(static_cast<size_t>(index->last_queries));
@@ -1560,6 +1617,17 @@ int ds_jaccard_topk_device(ds_index *index, const int64_t *d_q_rowptr, const int
                            const double *d_q_maxint, int64_t Q, int32_t k, int32_t *d_out_rows, void *stream)
 {
     return ds::launch(index, d_q_rowptr, d_q_cols, d_q_maxint, Q, k, d_out_rows, static_cast<hipStream_t>(stream));
+}
+
+int ds_index_option(ds_index *index, const char *name, int64_t value)
+{
+    DS_REQUIRE(index != nullptr && name != nullptr, "ds_index_option: null argument");
+    if (std::strcmp(name, "count_bytes") == 0) {
+        index->count_bytes = value != 0;
+        return DS_OK;
+    }
+    ds::set_error("ds_index_option: unknown option '%s'", name);
+    return DS_E_ARG;
 }
 
 int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[32])

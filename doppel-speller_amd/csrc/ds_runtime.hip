@@ -369,6 +369,30 @@ int ds_memset(void *dst, int value, size_t bytes, int device)
     return DS_OK;
 }
 
+int ds_memcpy_d2d_async(void *dst, const void *src, size_t bytes, int device, void *stream)
+{
+    DS_HIP(hipSetDevice(device));
+    if (bytes) DS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return DS_OK;
+}
+
+int ds_stream_create(int device, void **stream)
+{
+    DS_REQUIRE(stream != nullptr, "ds_stream_create: null pointer");
+    DS_HIP(hipSetDevice(device));
+    hipStream_t created = nullptr;
+    DS_HIP(hipStreamCreate(&created));
+    *stream = created;
+    return DS_OK;
+}
+
+int ds_stream_destroy(void *stream, int device)
+{
+    DS_HIP(hipSetDevice(device));
+    if (stream) DS_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return DS_OK;
+}
+
 int ds_stream_sync(void *stream, int device)
 {
     DS_HIP(hipSetDevice(device));

@@ -2,10 +2,22 @@
 
 Queries are independent (match_maker.py:192-203 is evaluated per row), so rank r of W owns the contiguous query range
 [Q*r/W, Q*(r+1)/W) and the truth index, title tables and word counts are replicated on every GPU.  The only
-collective is one all-gather of the int32[Q/W, k] row indexes (RCCL over xGMI when the backend is "nccl"; gloo in the
-CPU tests).  torch.distributed is plumbing only; nothing here computes.
+collective on the data path is one all-gather of the int32[Q/W, k] row indexes over RCCL (xGMI).
+
+No PyTorch anywhere: `Rendezvous` is a small TCP star through rank 0 (unique-id broadcast, host barrier, max of a
+float: what `bench.py` needs around the timed region) and `RcclCommunicator` binds librccl.so with ctypes
+(`ncclGetUniqueId`, `ncclCommInitRank`, `ncclAllGather` on the caller's HIP stream).  `HostCommunicator` has the same
+`all_gather` over host arrays through the rendezvous: the communicator the CPU tests inject.
 """
+import ctypes
+import os
+import socket
+import struct
+import time
+
 import numpy as np
+
+from . import _lib
 
 
 def shard_range(n_queries, rank, world_size):
@@ -20,33 +32,251 @@ def shard_sizes(n_queries, world_size):
             for r in range(world_size)]
 
 
-def gather_rows(local_rows, n_queries, group=None):
-    """All-gather the per-rank top-k rows (torch tensor int32[q_local, k], on the backend's device) into
-    int32[n_queries, k] in query order.  Shards may differ by one row; they are padded to the longest."""
-    import torch
-    import torch.distributed as dist
-    world_size = dist.get_world_size(group)
-    sizes = shard_sizes(n_queries, world_size)
-    longest = max(sizes)
-    k = local_rows.shape[1]
-    if local_rows.shape[0] != sizes[dist.get_rank(group)]:
-        raise ValueError("local_rows does not match this rank's shard size")
-    if local_rows.shape[0] == longest:
-        padded = local_rows.contiguous()
-    else:
-        padded = torch.full((longest, k), -1, dtype=local_rows.dtype, device=local_rows.device)
-        padded[:local_rows.shape[0]] = local_rows
-    gathered = torch.empty((world_size * longest, k), dtype=local_rows.dtype, device=local_rows.device)
-    dist.all_gather_into_tensor(gathered, padded, group=group)
-    if all(size == longest for size in sizes):
-        return gathered
-    pieces = [gathered[r * longest:r * longest + sizes[r]] for r in range(world_size)]
-    return torch.cat(pieces, dim=0)
-
-
 def slice_queries(q_rowptr, q_cols, q_maxint, begin, end):
     """The CSR slice of queries [begin, end) (host arrays)."""
     q_rowptr = np.asarray(q_rowptr)
     first, last = int(q_rowptr[begin]), int(q_rowptr[end])
     return (q_rowptr[begin:end + 1] - first).astype(np.int64), np.asarray(q_cols)[first:last], \
         np.asarray(q_maxint)[begin:end]
+
+
+# ---- rendezvous: TCP star through rank 0 ------------------------------------------------------------------------------
+def _send(sock, payload):
+    sock.sendall(struct.pack("<q", len(payload)) + payload)
+
+
+def _receive(sock):
+    def exactly(count):
+        chunks = []
+        while count:
+            chunk = sock.recv(min(count, 1 << 20))
+            if not chunk:
+                raise ConnectionError("rendezvous peer closed the connection")
+            chunks.append(chunk)
+            count -= len(chunk)
+        return b"".join(chunks)
+    (length,) = struct.unpack("<q", exactly(8))
+    return exactly(length)
+
+
+class Rendezvous:
+    """World-wide host-side exchange for one process per GPU: rank 0 listens on (address, port), every other rank
+    connects.  All operations are collective and must be called by every rank in the same order."""
+
+    def __init__(self, rank, world_size, address="127.0.0.1", port=29533, timeout=600.0):
+        self.rank, self.world_size = rank, world_size
+        self.peers = {}
+        self.server = None
+        if world_size == 1:
+            return
+        if rank == 0:
+            self.server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            self.server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            self.server.bind((address, port))
+            self.server.listen(world_size)
+            self.server.settimeout(timeout)
+            while len(self.peers) < world_size - 1:
+                connection, _ = self.server.accept()
+                connection.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                connection.settimeout(timeout)
+                (peer,) = struct.unpack("<i", _receive(connection))
+                self.peers[peer] = connection
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    connection = socket.create_connection((address, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            connection.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            connection.settimeout(timeout)
+            _send(connection, struct.pack("<i", rank))
+            self.peers[0] = connection
+
+    @classmethod
+    def from_environment(cls, port_offset=1):
+        """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as `torch.distributed.run` (or bench.py's own launcher) export
+        them; the launcher's store owns MASTER_PORT itself, so the star listens `port_offset` above it."""
+        return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+                   os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29533")) + port_offset)
+
+    def all_gather_bytes(self, payload):
+        """Every rank's payload, in rank order, on every rank."""
+        if self.world_size == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [_receive(self.peers[r]) for r in range(1, self.world_size)]
+            packed = b"".join(struct.pack("<q", len(p)) + p for p in parts)
+            for r in range(1, self.world_size):
+                _send(self.peers[r], packed)
+            return parts
+        _send(self.peers[0], payload)
+        packed, parts, at = _receive(self.peers[0]), [], 0
+        for _ in range(self.world_size):
+            (length,) = struct.unpack_from("<q", packed, at)
+            parts.append(packed[at + 8:at + 8 + length])
+            at += 8 + length
+        return parts
+
+    def broadcast_bytes(self, payload=None):
+        """Rank 0's payload on every rank."""
+        return self.all_gather_bytes(payload if self.rank == 0 else b"")[0]
+
+    def barrier(self):
+        self.all_gather_bytes(b"")
+
+    def max(self, value):
+        return max(struct.unpack("<d", part)[0] for part in self.all_gather_bytes(struct.pack("<d", float(value))))
+
+    def close(self):
+        for connection in self.peers.values():
+            connection.close()
+        if self.server is not None:
+            self.server.close()
+        self.peers, self.server = {}, None
+
+
+# ---- communicators ----------------------------------------------------------------------------------------------------
+class HostCommunicator:
+    """`all_gather` over host arrays through the rendezvous (CPU tests; same interface as RcclCommunicator)."""
+    on_device = False
+
+    def __init__(self, rendezvous):
+        self.rendezvous = rendezvous
+        self.rank, self.world_size = rendezvous.rank, rendezvous.world_size
+
+    def all_gather(self, send, stream=None):
+        """send: numpy array, same shape on every rank -> array [world_size * send.shape[0], ...] in rank order."""
+        send = np.ascontiguousarray(send)
+        parts = self.rendezvous.all_gather_bytes(send.tobytes())
+        return np.concatenate([np.frombuffer(p, dtype=send.dtype).reshape(send.shape) for p in parts])
+
+    def close(self):
+        pass
+
+
+class _NcclUniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_ubyte * 128)]
+
+
+_NCCL_TYPES = {np.dtype(np.int8): 0, np.dtype(np.uint8): 1, np.dtype(np.int32): 2, np.dtype(np.uint32): 3,
+               np.dtype(np.int64): 4, np.dtype(np.uint64): 5, np.dtype(np.float32): 7, np.dtype(np.float64): 8}
+
+
+def _load_rccl():
+    for name in (os.environ.get("DS_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
+                 "/opt/rocm/lib/librccl.so"):
+        if not name:
+            continue
+        try:
+            handle = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            continue
+        handle.ncclGetErrorString.restype = ctypes.c_char_p
+        handle.ncclGetErrorString.argtypes = [ctypes.c_int]
+        handle.ncclGetUniqueId.argtypes = [ctypes.POINTER(_NcclUniqueId)]
+        handle.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
+        handle.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_void_p]
+        handle.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        return handle
+    raise _lib.DoppelError("librccl.so not found (set DS_RCCL_LIBRARY)")
+
+
+class RcclCommunicator:
+    """One RCCL communicator over the ranks of the rendezvous (one process per GPU, device = LOCAL_RANK).
+
+    The unique id is created by rank 0 and broadcast through the rendezvous; `all_gather` enqueues ONE ncclAllGather
+    on the caller's HIP stream (device pointers in, device pointers out, no host staging)."""
+    on_device = True
+
+    def __init__(self, rendezvous, device):
+        self.rendezvous = rendezvous
+        self.rank, self.world_size, self.device = rendezvous.rank, rendezvous.world_size, device
+        self.rccl = _load_rccl()
+        _lib.check(_lib.lib().ds_stream_sync(None, device), "select device")  # hipSetDevice(device) for RCCL
+        unique = _NcclUniqueId()
+        if self.rank == 0:
+            self._check(self.rccl.ncclGetUniqueId(ctypes.byref(unique)), "ncclGetUniqueId")
+        raw = rendezvous.broadcast_bytes(ctypes.string_at(ctypes.byref(unique), 128) if self.rank == 0 else None)
+        if len(raw) != 128:
+            raise _lib.DoppelError("rendezvous delivered a malformed RCCL unique id")
+        ctypes.memmove(ctypes.byref(unique), raw, 128)
+        self.comm = ctypes.c_void_p()
+        self._check(self.rccl.ncclCommInitRank(ctypes.byref(self.comm), self.world_size, unique, self.rank),
+                    "ncclCommInitRank")
+
+    def _check(self, status, what):
+        if status != 0:
+            raise _lib.DoppelError(f"{what}: {self.rccl.ncclGetErrorString(status).decode()} (rccl status {status})")
+
+    def all_gather(self, send, stream=None, out=None):
+        """send: DeviceArray, same shape on every rank -> DeviceArray [world_size * send.shape[0], ...]."""
+        if out is None:
+            out = _lib.DeviceArray((self.world_size * send.shape[0],) + tuple(send.shape[1:]), send.dtype, self.device)
+        count = int(np.prod(send.shape, dtype=np.int64))
+        self._check(self.rccl.ncclAllGather(send.ptr, out.ptr, count, _NCCL_TYPES[send.dtype], self.comm,
+                                            ctypes.c_void_p(stream or 0)), "ncclAllGather")
+        return out
+
+    def close(self):
+        if getattr(self, "comm", None):
+            self.rccl.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+class RowGather:
+    """The one collective of the path: every rank's int32[q_local, k] top-k rows -> int32[n_queries, k] in query
+    order on every rank.  Shards may differ by one row; they travel padded to the longest shard and are compacted
+    afterwards.  Buffers are allocated once and reused by every `gather` (nothing is allocated in a timed region)."""
+
+    def __init__(self, communicator, n_queries, k, device=0):
+        self.communicator, self.n_queries, self.k, self.device = communicator, n_queries, k, device
+        self.sizes = shard_sizes(n_queries, communicator.world_size)
+        self.longest = max(self.sizes)
+        self.even = all(size == self.longest for size in self.sizes)
+        self.local = self.sizes[communicator.rank]
+        self.padded = self.gathered = self.compact = None
+        if communicator.on_device:
+            world = communicator.world_size
+            self.gathered = _lib.DeviceArray((world * self.longest, k), np.int32, device)
+            if not self.even:
+                self.padded = _lib.DeviceArray((self.longest, k), np.int32, device)
+                _lib.check(_lib.lib().ds_memset(self.padded.ptr, 0xff, self.padded.nbytes, device), "pad")
+                self.compact = _lib.DeviceArray((n_queries, k), np.int32, device)
+
+    def gather(self, local_rows, stream=None):
+        """local_rows: numpy int32[q_local, k] (HostCommunicator) or DeviceArray / device pointer (RcclCommunicator)."""
+        if not self.communicator.on_device:
+            local_rows = np.ascontiguousarray(local_rows, dtype=np.int32)
+            if local_rows.shape != (self.local, self.k):
+                raise ValueError("local_rows does not match this rank's shard")
+            padded = np.full((self.longest, self.k), -1, dtype=np.int32)
+            padded[:self.local] = local_rows
+            gathered = self.communicator.all_gather(padded)
+            return np.concatenate([gathered[r * self.longest:r * self.longest + size]
+                                   for r, size in enumerate(self.sizes)])
+        lib, row_bytes = _lib.lib(), self.k * 4
+        if isinstance(local_rows, _lib.DeviceArray):
+            pointer = local_rows.ptr
+        else:
+            pointer = local_rows if isinstance(local_rows, ctypes.c_void_p) else ctypes.c_void_p(int(local_rows))
+        stream_pointer = ctypes.c_void_p(stream or 0)
+        send = _lib.DeviceArray.view(pointer, (self.longest, self.k), np.int32, self.device)
+        if not self.even:
+            _lib.check(lib.ds_memcpy_d2d_async(self.padded.ptr, pointer, self.local * row_bytes, self.device,
+                                               stream_pointer), "pad copy")
+            send = self.padded
+        self.communicator.all_gather(send, stream, out=self.gathered)
+        if self.even:
+            return self.gathered
+        at = 0
+        for r, size in enumerate(self.sizes):
+            source = ctypes.c_void_p(self.gathered.ptr.value + r * self.longest * row_bytes)
+            target = ctypes.c_void_p(self.compact.ptr.value + at * row_bytes)
+            _lib.check(lib.ds_memcpy_d2d_async(target, source, size * row_bytes, self.device, stream_pointer), "compact")
+            at += size
+        return self.compact

@@ -68,6 +68,10 @@ class TruthIndex:
         keys = ("n_truth", "n_columns", "nnz", "tile_rows", "tiles", "device_bytes", "padded_postings")
         return dict(zip(keys, list(raw)[:7]))
 
+    def option(self, name, value):
+        """Diagnostics switch of the index (ds_index_option), e.g. option("count_bytes", 1)."""
+        _lib.check(_lib.lib().ds_index_option(self.handle, name.encode(), int(value)), "ds_index_option")
+
     def top_k(self, q_rowptr, q_cols, q_maxint, k):
         """fast_jaccard + fast_arg_top_k for a batch: int32[Q, k] truth rows, descending row index per query."""
         q_rowptr = np.ascontiguousarray(q_rowptr, dtype=np.int64)
@@ -97,6 +101,7 @@ class TruthIndex:
         return {"dense_queries": stats[0], "error_queries": stats[1], "exact_candidates": stats[2],
                 "selections": stats[3], "phase_cycles": dict(zip(names, list(stats)[4:12])),
                 "sparse_tiles": stats[12], "dense_tiles": stats[13], "skipped_columns": stats[14],
+                "requested_bytes": stats[15],
                 "dense_reasons": dict(zip(("shape", "items", "overflow_sparse", "overflow_dense", "ties", "few"),
                                           list(stats)[16:22])),
                 "refines": stats[22], "raw_entries": stats[23], "refine_survivors": stats[24],

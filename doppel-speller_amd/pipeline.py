@@ -16,8 +16,7 @@ from .match_maker import TruthIndex
 class CandidatePipeline:
     def __init__(self, workload, k, device=0, q_begin=0, q_end=None, rows_ptr=None):
         """workload: an object with the fields of synth.make_workload.  Queries [q_begin, q_end) are this GPU's shard.
-        rows_ptr: optional device pointer of an int32[q, k] buffer owned by the caller (e.g. a torch tensor that is
-        later all-gathered); allocated here when omitted."""
+        rows_ptr: optional device pointer of an int32[q, k] buffer owned by the caller; allocated here when omitted."""
         from .distributed import slice_queries
         self.k = k
         self.device = device
@@ -89,5 +88,10 @@ class CandidatePipeline:
         _lib.check(_lib.lib().ds_memcpy_d2h(_lib.pointer(out), self.rows_ptr, out.nbytes, self.device), "d2h")
         return out
 
-    def features(self):
-        return self.d_features.to_host()
+    def features(self, n_pairs=None):
+        """float32[n_pairs, 66] of the last `enqueue_features` (all pairs by default; the first n_pairs otherwise)."""
+        if n_pairs is None:
+            return self.d_features.to_host()
+        out = np.empty((n_pairs, FEATURES_COUNT), dtype=np.float32)
+        _lib.check(_lib.lib().ds_memcpy_d2h(_lib.pointer(out), self.d_features.ptr, out.nbytes, self.device), "d2h")
+        return out

@@ -65,6 +65,10 @@ void ds_index_destroy(ds_index *index);
  * LARGEST ROW INDEXES at or above its threshold (match_maker.py:71): a row of rank >= k can never be returned. */
 int ds_index_duplicate_ranks(const int64_t *rowptr, const int32_t *truth_idx, const float *sums32, int64_t V, int64_t N,
                              uint16_t *rank_out);
+/* Diagnostics switches of an index.  "count_bytes" (0 / 1): the next ds_jaccard_topk* calls run the instantiation of
+ * the fast kernel that also counts the bytes it requests from global memory (reported by ds_jaccard_sync, stats[15]);
+ * same work, same results, about 3 % slower -- bench.py runs it once outside the timed region for its roofline. */
+int ds_index_option(ds_index *index, const char *name, int64_t value);
 /* info[0]=N info[1]=V info[2]=nnz info[3]=tile size info[4]=tiles info[5]=device bytes info[6]=padded postings */
 int ds_index_info(const ds_index *index, int64_t info[8]);
 
@@ -178,6 +182,9 @@ int ds_free(void *ptr, int device);
 int ds_memcpy_h2d(void *dst, const void *src, size_t bytes, int device);
 int ds_memcpy_d2h(void *dst, const void *src, size_t bytes, int device);
 int ds_memset(void *dst, int value, size_t bytes, int device);
+int ds_memcpy_d2d_async(void *dst, const void *src, size_t bytes, int device, void *stream);
+int ds_stream_create(int device, void **stream);   /* a HIP stream for the _device entry points and RCCL */
+int ds_stream_destroy(void *stream, int device);
 int ds_stream_sync(void *stream, int device);
 int ds_timer_create(int device, ds_timer **out);
 void ds_timer_destroy(ds_timer *timer);

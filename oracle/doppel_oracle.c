@@ -42,6 +42,15 @@
 #define DS_FEATURES 66       /* feature_engineering.py:67 */
 #define DS_MAX_CHARS 255     /* settings.py:68 */
 
+void ds_oracle_set_num_threads(int threads)
+{
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+}
+
 int ds_oracle_num_threads(void)
 {
 #ifdef _OPENMP

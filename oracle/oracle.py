@@ -51,6 +51,11 @@ def num_threads():
     return int(lib().ds_oracle_num_threads())
 
 
+def set_num_threads(threads):
+    """OpenMP threads of the batched entry points (bench.py's cpu_baseline sweeps this)."""
+    lib().ds_oracle_set_num_threads(ctypes.c_int(int(threads)))
+
+
 def fast_jaccard(max_intersection_possible, columns, rowptr, truth_idx, idf32, sums32):
     """match_maker.py:16-50 -> float64[N]."""
     n = sums32.shape[0]

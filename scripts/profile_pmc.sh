@@ -15,17 +15,5 @@ run write WRITE_SIZE
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU
 run sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
 run tcc TCC_HIT_sum TCC_MISS_sum
-python3 - <<PY
-import csv, glob, collections
-for name in ("fetch","write","sq1","sq2","tcc"):
-    files = glob.glob("gpurun_out/pmc_${tag}_%s/**/*counter_collection.csv" % name, recursive=True)
-    agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
-    for f in files:
-        for row in csv.DictReader(open(f)):
-            k = row["Kernel_Name"].split("(")[0]
-            agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
-            calls[(k, row["Counter_Name"])] += 1
-    for k, counters in agg.items():
-        for c, v in counters.items():
-            print(name, k, c, "total=%.6g" % v, "dispatches=%d" % calls[(k, c)], "per_dispatch=%.6g" % (v / calls[(k, c)]))
-PY
+python3 scripts/pmc_summary.py ${tag} 100000 500000 10 --write | tee gpurun_out/pmc_${tag}_summary.txt
+cp profiles/pmc_latest.json gpurun_out/pmc_${tag}_latest.json

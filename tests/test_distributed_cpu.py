@@ -1,6 +1,9 @@
-"""World-size-2 gloo test of the query-sharding path: shard ranges, CSR slicing and the single all-gather of the
-top-k rows.  No GPU here, so each rank's shard is computed by the oracle (test infrastructure) -- the code under test
-is doppel-speller_amd/distributed.py, which never computes anything itself."""
+"""CPU tests of the query-sharding path: shard ranges, CSR slicing, the TCP rendezvous and the single gather of the
+top-k rows with the injectable host communicator (world sizes 2 and 3, fresh child processes).  No GPU here, so each
+rank's shard is computed by the oracle (test infrastructure) -- the code under test is
+doppel-speller_amd/distributed.py, which never computes anything itself.  The RCCL communicator has the same
+`all_gather` interface and is exercised on the GPU box (tests/test_gpu_distributed.py)."""
+import multiprocessing
 import os
 import socket
 import sys
@@ -31,37 +34,58 @@ def test_slice_queries_round_trip():
     assert all(p[0][0] == 0 and p[0][-1] == p[1].shape[0] for p in pieces)
 
 
+def test_product_package_does_not_import_torch():
+    """north_star: host code is Python over a thin C ABI, no PyTorch -- not even for the multi-GPU plumbing."""
+    import subprocess
+    script = ("import sys; sys.path.insert(0, %r); import doppel_speller_amd, doppel_speller_amd.distributed; "
+              "assert 'torch' not in sys.modules, 'torch was imported'; print('clean')" % ROOT)
+    result = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=120)
+    assert result.returncode == 0 and "clean" in result.stdout, result.stderr[-1000:]
+    for name in os.listdir(os.path.join(ROOT, "doppel-speller_amd")):
+        if name.endswith(".py"):
+            with open(os.path.join(ROOT, "doppel-speller_amd", name)) as handle:
+                assert "import torch" not in handle.read(), name
+    with open(os.path.join(ROOT, "bench.py")) as handle:
+        assert "import torch" not in handle.read()
+
+
 def _worker(rank, world, port, n_queries, result_path):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
-    import torch
-    import torch.distributed as dist
     from doppel_speller_amd import synth
-    from doppel_speller_amd.distributed import gather_rows, shard_range, slice_queries
+    from doppel_speller_amd.distributed import HostCommunicator, Rendezvous, RowGather, shard_range, slice_queries
     from oracle import oracle
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rendezvous = Rendezvous(rank, world, "127.0.0.1", port, timeout=120.0)
+    assert rendezvous.broadcast_bytes(b"unique-id" if rank == 0 else None) == b"unique-id"
+    assert rendezvous.max(float(rank)) == float(world - 1)
     w = synth.make_workload(3000, n_queries, seed=11)
     begin, end = shard_range(n_queries, rank, world)
     rowptr, cols, maxint = slice_queries(w.q_rowptr, w.q_cols, w.q_maxint, begin, end)
     local = oracle.jaccard_topk(w.rowptr, w.truth_idx, w.idf32, w.sums32, rowptr, cols, maxint, 10)
-    gathered = gather_rows(torch.from_numpy(local), n_queries)
-    if rank == 0:
-        np.save(result_path, gathered.numpy())
-    dist.barrier()
-    dist.destroy_process_group()
+    gather = RowGather(HostCommunicator(rendezvous), n_queries, 10)
+    for _ in range(2):  # buffers are reused from call to call
+        gathered = gather.gather(local)
+    rendezvous.barrier()
+    np.save(f"{result_path}.{rank}.npy", gathered)
+    rendezvous.close()
 
 
-@pytest.mark.parametrize("n_queries", [64, 65])
-def test_two_rank_gather_matches_single_process(tmp_path, n_queries):
-    import torch.multiprocessing as mp
+@pytest.mark.parametrize("world,n_queries", [(2, 64), (2, 65), (3, 100)])
+def test_gather_matches_single_process(tmp_path, world, n_queries):
     from doppel_speller_amd import synth
     from oracle import oracle
     oracle.build()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    result = str(tmp_path / "rows.npy")
-    mp.spawn(_worker, args=(2, port, n_queries, result), nprocs=2, join=True)
+    result = str(tmp_path / "rows")
+    context = multiprocessing.get_context("spawn")
+    ranks = [context.Process(target=_worker, args=(r, world, port, n_queries, result)) for r in range(world)]
+    for process in ranks:
+        process.start()
+    for process in ranks:
+        process.join(300)
+        assert process.exitcode == 0
     w = synth.make_workload(3000, n_queries, seed=11)
     expected = oracle.jaccard_topk(w.rowptr, w.truth_idx, w.idf32, w.sums32, w.q_rowptr, w.q_cols, w.q_maxint, 10)
-    assert np.array_equal(np.load(result), expected)
+    for rank in range(world):   # an all-gather: every rank holds all rows, in query order
+        assert np.array_equal(np.load(f"{result}.{rank}.npy"), expected)

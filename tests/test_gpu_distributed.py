@@ -1,0 +1,49 @@
+"""GPU-box rehearsal of the multi-GPU plumbing with the one GPU a test box has: the RCCL communicator (ctypes binding
+of librccl, unique id through the rendezvous, ONE ncclAllGather on a HIP stream) with a single rank, and bench.py's
+own rank launcher with the host communicator.  Real N > 1 RCCL runs need N GPUs: bench.py --gpus N."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rccl_single_rank_gather_on_device(oracle):
+    import ctypes
+    import doppel_speller_amd as ds
+    from doppel_speller_amd import _lib, synth
+    from doppel_speller_amd.distributed import RcclCommunicator, Rendezvous, RowGather
+    w = synth.make_workload(30000, 257, seed=19)
+    pipeline = ds.CandidatePipeline(w, 10)
+    stream = ctypes.c_void_p()
+    _lib.check(_lib.lib().ds_stream_create(0, ctypes.byref(stream)), "stream")
+    communicator = RcclCommunicator(Rendezvous(0, 1), 0)
+    gather = RowGather(communicator, 257, 10)
+    pipeline.enqueue_top_k(stream.value)
+    gathered = gather.gather(pipeline.rows_ptr, stream.value)   # the ncclAllGather follows the kernels on the stream
+    _lib.check(_lib.lib().ds_stream_sync(stream, 0), "sync")
+    expected = oracle.jaccard_topk(w.rowptr, w.truth_idx, w.idf32, w.sums32, w.q_rowptr, w.q_cols, w.q_maxint, 10)
+    assert np.array_equal(gathered.to_host(), expected)
+    communicator.close()
+    _lib.check(_lib.lib().ds_stream_destroy(stream, 0), "stream")
+
+
+def test_bench_spawns_its_own_ranks():
+    """`bench.py --gpus 2` without a launcher starts two fresh rank processes (both on the box's only GPU here, hence
+    the host communicator) and rank 0 prints one JSON line for the whole job."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env["DS_BENCH_SAME_DEVICE"] = "1"
+    result = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--queries", "2000",
+                             "--truth", "60000", "--k", "10", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0",
+                             "--check", "32", "--host-communicator"], env=env, capture_output=True, text=True,
+                            timeout=600)
+    assert result.returncode == 0, result.stderr[-3000:]
+    line = json.loads(result.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["queries_per_gpu"] == 2000 and line["verified_queries"] == 32
+    assert line["value"] > 0 and line["roofline"]["frac"] <= 1.0
