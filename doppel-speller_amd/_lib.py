@@ -7,7 +7,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-_SOURCES = ("ds_runtime.hip", "ds_jaccard.hip", "ds_features.hip", "ds_build.hip", "ds_forest.hip")
+_SOURCES = ("ds_runtime.hip", "ds_jaccard.hip", "ds_features.hip", "ds_build.hip", "ds_forest.hip", "ds_pairs.hip")
 _lib = None
 
 
@@ -82,6 +82,7 @@ def _declare(handle):
         "ds_jaccard_topk": [p, p, p, p, c.c_int64, c.c_int32, p],
         "ds_jaccard_topk_device": [p, p, p, p, c.c_int64, c.c_int32, p, p],
         "ds_jaccard_sync": [p, p, c.POINTER(c.c_int64)],
+        "ds_jaccard_status": [p, p, p, c.c_int64],
         "ds_construct_features": [p, p, p, p, p, c.c_uint8, c.c_uint32, c.c_int64, c.c_int64, c.c_int, p],
         "ds_titles_create": [p, c.c_int64, p, p, c.c_int64, c.c_int, c.POINTER(p)],
         "ds_construct_features_indexed": [p, p, p, p, c.c_uint8, c.c_uint32, c.c_int64, p],
@@ -90,6 +91,8 @@ def _declare(handle):
         "ds_levenshtein_ratio_batch": [p, p, p, p, c.c_int64, c.c_int, c.c_int, p],
         "ds_close_matches": [p, p, p, c.c_int32, c.c_int64, c.c_uint8, p, c.c_int32, p, p],
         "ds_close_matches_device": [p, p, p, c.c_int64, c.c_int32, c.c_int64, c.c_uint8, p, c.c_int32, p, p, p],
+        "ds_remaining_pairs_device": [p, p, c.c_int64, c.c_int32, c.c_int64, p, p, p, p],
+        "ds_select_matches_device": [p, p, p, c.c_int64, c.c_int32, c.c_float, p, p, p],
         "ds_problem_create": [p, p, c.c_int64, p, p, c.c_int64, c.c_int32, c.POINTER(p)],
         "ds_problem_info": [p, c.POINTER(c.c_int64)],
         "ds_problem_arrays": [p] + [c.POINTER(p)] * 9,
@@ -115,6 +118,8 @@ def _declare(handle):
         function = getattr(handle, name)
         function.argtypes = argtypes
         function.restype = c.c_int
+    handle.ds_remaining_pairs_counts_size.argtypes = [c.c_int64]
+    handle.ds_remaining_pairs_counts_size.restype = c.c_int64
     for name in ("ds_index_destroy", "ds_titles_destroy", "ds_timer_destroy", "ds_problem_destroy", "ds_forest_destroy"):
         function = getattr(handle, name)
         function.argtypes = [p]
@@ -125,9 +130,10 @@ def _declare(handle):
 EXPORTED_SYMBOLS = (
     "ds_last_error", "ds_version", "ds_build_id", "ds_device_count", "ds_device_name", "ds_index_create", "ds_index_destroy",
     "ds_index_duplicate_ranks", "ds_index_option",
-    "ds_index_info", "ds_jaccard_topk", "ds_jaccard_topk_device", "ds_jaccard_sync", "ds_construct_features",
+    "ds_index_info", "ds_jaccard_topk", "ds_jaccard_topk_device", "ds_jaccard_sync", "ds_jaccard_status", "ds_construct_features",
     "ds_titles_create", "ds_titles_destroy", "ds_construct_features_indexed", "ds_construct_features_indexed_device",
-    "ds_levenshtein_ratio_batch", "ds_close_matches", "ds_close_matches_device", "ds_problem_create",
+    "ds_levenshtein_ratio_batch", "ds_close_matches", "ds_close_matches_device", "ds_remaining_pairs_counts_size", "ds_remaining_pairs_device",
+    "ds_select_matches_device", "ds_problem_create",
     "ds_problem_destroy", "ds_problem_info", "ds_problem_arrays", "ds_transform_titles", "ds_forest_create", "ds_forest_destroy",
     "ds_forest_predict", "ds_forest_predict_device", "ds_malloc", "ds_free", "ds_memcpy_h2d", "ds_memcpy_d2h", "ds_memset",
     "ds_stream_sync", "ds_memcpy_d2d_async", "ds_stream_create", "ds_stream_destroy", "ds_timer_create", "ds_timer_destroy", "ds_timer_start", "ds_timer_stop",

@@ -1619,6 +1619,18 @@ int ds_jaccard_topk_device(ds_index *index, const int64_t *d_q_rowptr, const int
     return ds::launch(index, d_q_rowptr, d_q_cols, d_q_maxint, Q, k, d_out_rows, static_cast<hipStream_t>(stream));
 }
 
+int ds_jaccard_status(ds_index *index, void *stream, int32_t *status, int64_t Q)
+{
+    DS_REQUIRE(index != nullptr && status != nullptr, "ds_jaccard_status: null argument");
+    DS_REQUIRE(Q == index->last_queries, "ds_jaccard_status: Q=%lld but the last call had %lld queries", (long long)Q,
+               (long long)index->last_queries);
+    if (Q == 0) return DS_OK;
+    DS_HIP(hipSetDevice(index->device));
+    DS_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    DS_HIP(hipMemcpy(status, index->status.ptr, static_cast<size_t>(Q) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return DS_OK;
+}
+
 int ds_index_option(ds_index *index, const char *name, int64_t value)
 {
     DS_REQUIRE(index != nullptr && name != nullptr, "ds_index_option: null argument");

@@ -108,6 +108,13 @@ class TruthIndex:
                 "raw_entries_sparse": stats[25], "topk_kernel_ms": stats[26] / 1000.0,
                 "dense_kernel_ms": stats[27] / 1000.0, "bounds_record": list(stats)[28:32]}
 
+    def status(self, n_queries, stream=None):
+        """int32[n_queries] of the last call: 0 fast kernel, 1 literal kernel, 2 fewer than k rows, 3 bad column."""
+        out = np.empty(n_queries, dtype=np.int32)
+        _lib.check(_lib.lib().ds_jaccard_status(self.handle, ctypes.c_void_p(stream or 0), _lib.pointer(out),
+                                                n_queries), "ds_jaccard_status")
+        return out
+
     def close(self):
         if self.handle:
             _lib.lib().ds_index_destroy(self.handle)

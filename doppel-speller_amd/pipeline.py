@@ -10,6 +10,8 @@ import numpy as np
 
 from . import _lib
 from .feature_engineering import FEATURES_COUNT, LEVENSHTEIN_RATIO_THRESHOLD, SORT_KEY, SPACE_CODE, TitleTable
+
+PREDICTION_PROBABILITY_THRESHOLD = 0.9  # settings.py:76
 from .match_maker import TruthIndex
 
 
@@ -38,6 +40,8 @@ class CandidatePipeline:
         self.d_features = _lib.DeviceArray((self.n_queries * k, FEATURES_COUNT), np.float32, device)
         self._close = None
         self._predictions = None
+        self._pairs = None
+        self._matches = None
 
     def enqueue_top_k(self, stream=None):
         self.index.top_k_device(self.d_rowptr.ptr, self.d_cols.ptr, self.d_maxint.ptr, self.n_queries, self.k,
@@ -67,14 +71,63 @@ class CandidatePipeline:
         ratios, best, _ = self._close
         return ratios.to_host(), best.to_host()
 
-    def enqueue_predict(self, model, stream=None):
+    def enqueue_remaining_pairs(self, stream=None):
+        """Next row f-2 (predict.py:172-183): drop the queries the fuzzy step matched (`enqueue_close_matches` first)
+        and compact the (query row, truth row) pairs of the others, in order, on the device."""
+        if self._pairs is None:
+            size = int(_lib.lib().ds_remaining_pairs_counts_size(self.n_queries))
+            self._pairs = (_lib.DeviceArray((self.n_queries * self.k,), np.int32, self.device),
+                           _lib.DeviceArray((self.n_queries * self.k,), np.int32, self.device),
+                           _lib.DeviceArray((size,), np.int64, self.device))
+        pair_q, pair_t, counts = self._pairs
+        _lib.check(_lib.lib().ds_remaining_pairs_device(self._close[1].ptr, self.rows_ptr, self.n_queries, self.k, 0,
+                                                        pair_q.ptr, pair_t.ptr, counts.ptr,
+                                                        ctypes.c_void_p(stream or 0)), "ds_remaining_pairs_device")
+
+    def remaining_counts(self, stream=None):
+        """(remaining queries, pairs) of the last `enqueue_remaining_pairs` (synchronises the stream)."""
+        _lib.check(_lib.lib().ds_stream_sync(ctypes.c_void_p(stream or 0), self.device), "sync")
+        out = np.empty(2, dtype=np.int64)
+        _lib.check(_lib.lib().ds_memcpy_d2h(_lib.pointer(out), self._pairs[2].ptr, 16, self.device), "d2h")
+        return int(out[0]), int(out[1])
+
+    def remaining_pairs(self, n_pairs):
+        pair_q, pair_t, _ = self._pairs
+        return pair_q.to_host()[:n_pairs], pair_t.to_host()[:n_pairs]
+
+    def enqueue_features_remaining(self, n_pairs, stream=None):
+        """construct_features on the compacted pair list only (predict.py:195-219), into the first n_pairs rows."""
+        pair_q, pair_t, _ = self._pairs
+        _lib.check(_lib.lib().ds_construct_features_indexed_device(
+            self.query_titles.handle, self.truth_titles.handle, pair_q.ptr, pair_t.ptr, 0, self.k, SPACE_CODE,
+            self.n_truth, n_pairs, self.d_features.ptr, ctypes.c_void_p(stream or 0)),
+            "ds_construct_features_indexed_device")
+
+    def enqueue_predict(self, model, stream=None, n_pairs=None):
         """Next row f-4: the tree ensemble (predict.py:229-234) on the feature matrix resident in HBM."""
         if self._predictions is None:
             self._predictions = _lib.DeviceArray((self.n_queries * self.k,), np.float32, self.device)
-        model.predict_device(self.d_features.ptr, self.n_queries * self.k, None, self._predictions.ptr, stream)
+        n_pairs = self.n_queries * self.k if n_pairs is None else n_pairs
+        model.predict_device(self.d_features.ptr, n_pairs, None, self._predictions.ptr, stream)
 
-    def predictions(self):
-        return self._predictions.to_host().reshape(self.n_queries, self.k)
+    def enqueue_select_matches(self, n_remaining, threshold=PREDICTION_PROBABILITY_THRESHOLD, stream=None):
+        """predict.py:246-252 on the predictions of the compacted pairs: per remaining query the single pair with the
+        maximum prediction above the threshold."""
+        if self._matches is None:
+            self._matches = (_lib.DeviceArray((self.n_queries,), np.int32, self.device),
+                             _lib.DeviceArray((self.n_queries,), np.int32, self.device))
+        pair_q, pair_t, _ = self._pairs
+        _lib.check(_lib.lib().ds_select_matches_device(pair_q.ptr, pair_t.ptr, self._predictions.ptr, n_remaining, self.k,
+                                                       float(threshold), self._matches[0].ptr, self._matches[1].ptr,
+                                                       ctypes.c_void_p(stream or 0)), "ds_select_matches_device")
+
+    def matches(self, n_remaining):
+        """(query rows, matched truth row or -1) of the last `enqueue_select_matches`."""
+        return self._matches[0].to_host()[:n_remaining], self._matches[1].to_host()[:n_remaining]
+
+    def predictions(self, n_pairs=None):
+        out = self._predictions.to_host()
+        return out.reshape(self.n_queries, self.k) if n_pairs is None else out[:n_pairs]
 
     def step(self, stream=None):
         self.enqueue_top_k(stream)
@@ -88,10 +141,22 @@ class CandidatePipeline:
         _lib.check(_lib.lib().ds_memcpy_d2h(_lib.pointer(out), self.rows_ptr, out.nbytes, self.device), "d2h")
         return out
 
-    def features(self, n_pairs=None):
-        """float32[n_pairs, 66] of the last `enqueue_features` (all pairs by default; the first n_pairs otherwise)."""
+    def features_of(self, queries):
+        """float32[len(queries) * k, 66]: the feature rows of the given queries' pairs (one small copy per query)."""
+        queries = np.asarray(queries, dtype=np.int64)
+        out = np.empty((queries.shape[0] * self.k, FEATURES_COUNT), dtype=np.float32)
+        row_bytes = FEATURES_COUNT * 4 * self.k
+        for i, q in enumerate(queries):
+            source = ctypes.c_void_p(self.d_features.ptr.value + int(q) * row_bytes)
+            _lib.check(_lib.lib().ds_memcpy_d2h(ctypes.c_void_p(out.ctypes.data + i * row_bytes), source, row_bytes,
+                                                self.device), "d2h")
+        return out
+
+    def features(self, n_pairs=None, first_pair=0):
+        """float32[n_pairs, 66] of the last `enqueue_features`, pairs [first_pair, first_pair + n_pairs) (default: all)."""
         if n_pairs is None:
-            return self.d_features.to_host()
+            n_pairs = self.n_queries * self.k - first_pair
         out = np.empty((n_pairs, FEATURES_COUNT), dtype=np.float32)
-        _lib.check(_lib.lib().ds_memcpy_d2h(_lib.pointer(out), self.d_features.ptr, out.nbytes, self.device), "d2h")
+        source = ctypes.c_void_p(self.d_features.ptr.value + first_pair * FEATURES_COUNT * 4)
+        _lib.check(_lib.lib().ds_memcpy_d2h(_lib.pointer(out), source, out.nbytes, self.device), "d2h")
         return out

@@ -94,6 +94,10 @@ int ds_jaccard_topk_device(ds_index *index, const int64_t *d_q_rowptr, const int
  * stats[26]=duration of ds_jaccard_topk_kernel in microseconds (HIP events on the launch stream),
  * stats[27]=duration of ds_jaccard_dense_kernel in microseconds. */
 int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[32]);
+/* Per-query status of the last call (after synchronising `stream`): 0 = answered by the fast kernel, 1 = handed to and
+ * answered by the literal kernel, 2 = fewer than k rows qualified (DS_E_TOP_N), 3 = bad column index (DS_E_ARG).
+ * stats[15] of ds_jaccard_sync = bytes requested by the fast kernel (only with ds_index_option "count_bytes"). */
+int ds_jaccard_status(ds_index *index, void *stream, int32_t *status, int64_t Q);
 
 /* ---- Levenshtein / features:  fast_levenshtein_ratio + construct_features (feature_engineering.py:25-169) ------- */
 /* The 9-argument gufunc of feature_engineering.py:69-80 without the `dummy` argument: rows of q_enc / t_enc are
@@ -136,6 +140,22 @@ int ds_close_matches(ds_titles *queries, ds_titles *truth, const int32_t *pair_t
 int ds_close_matches_device(ds_titles *queries, ds_titles *truth, const int32_t *d_pair_t, int64_t q_first, int32_t k,
                             int64_t n_queries, uint8_t space_code, const uint8_t *d_sort_key, int32_t threshold,
                             uint8_t *d_ratios, int32_t *d_best_row, void *stream);
+
+/* ---- next row f-2: the pair list between the fuzzy step and the model, on the device (predict.py:172-183,195-204) ---
+ * d_best_row[q] >= 0 marks a query the fuzzy step matched (ds_close_matches_device).  The remaining queries keep
+ * their order; each contributes its k candidate rows d_rows[q*k .. q*k+k) in order: d_pair_q / d_pair_t (room for
+ * n_queries * k entries) receive the (query row, truth row) index pairs for ds_construct_features_indexed_device,
+ * query rows offset by q_first.  d_counts = int64[ds_remaining_pairs_counts_size(n_queries)]: [0] = remaining
+ * queries, [1] = pairs, the rest is scratch.  Asynchronous on `stream`. */
+int64_t ds_remaining_pairs_counts_size(int64_t n_queries);
+int ds_remaining_pairs_device(const int32_t *d_best_row, const int32_t *d_rows, int64_t n_queries, int32_t k,
+                              int64_t q_first, int32_t *d_pair_q, int32_t *d_pair_t, int64_t *d_counts, void *stream);
+/* predict.py:246-252 for n_remaining queries of k consecutive pairs each: d_match_query[r] = the query row of group
+ * r, d_match_row[r] = the truth row of its maximum prediction when that maximum is above `threshold`
+ * (PREDICTION_PROBABILITY_THRESHOLD, settings.py:76) and a single pair holds it, else -1. */
+int ds_select_matches_device(const int32_t *d_pair_q, const int32_t *d_pair_t, const float *d_predictions,
+                             int64_t n_remaining, int32_t k, float threshold, int32_t *d_match_query,
+                             int32_t *d_match_row, void *stream);
 
 /* ---- next row f-3: native index build ----------------------------------------------------------------------------
  * Replaces the Python / lil_matrix loops of MatchMaker.__init__ (doppelspeller/match_maker.py:84-181) and

@@ -184,3 +184,25 @@ def forest_predict(forest, rows):
         _ptr(rows, ctypes.c_float), ctypes.c_int64(n), ctypes.c_int64(rows.shape[1]),
         _ptr(margins, ctypes.c_float), _ptr(probabilities, ctypes.c_float))
     return margins, probabilities
+
+
+def remaining_pairs(best_row, rows):
+    """predict.py:172-183 restated in NumPy: the (query row, truth row) pairs of the queries the fuzzy step did NOT
+    match (best_row < 0), in the order of the reference's `remaining` frame (query-major, candidates in order)."""
+    best_row, rows = np.asarray(best_row), np.asarray(rows)
+    kept = np.nonzero(best_row < 0)[0]
+    k = rows.shape[1]
+    return np.repeat(kept, k).astype(np.int32), rows[kept].reshape(-1).astype(np.int32)
+
+
+def select_matches(pair_q, pair_t, predictions, k, threshold=0.9):
+    """predict.py:246-252 (+ :158-161) restated: per query (k consecutive pairs) the rows holding the maximum
+    prediction, of those the ones above the threshold, and a match only when exactly one row is left."""
+    pair_q, pair_t = np.asarray(pair_q).reshape(-1, k), np.asarray(pair_t).reshape(-1, k)
+    predictions = np.asarray(predictions, dtype=np.float32).reshape(-1, k)
+    best = predictions.max(axis=1, keepdims=True)
+    holds = (predictions == best) & (predictions > np.float32(threshold))
+    single = holds.sum(axis=1) == 1
+    where = holds.argmax(axis=1)
+    match = np.where(single, pair_t[np.arange(pair_t.shape[0]), where], -1).astype(np.int32)
+    return pair_q[:, 0].astype(np.int32), match

@@ -1,0 +1,86 @@
+"""BASELINE.json's single-GPU configurations at their FULL size through the fused device-resident path:
+C2 = 100k queries x 500k truth titles, top-10; C3 = 1M queries x 5M truth titles, top-50.
+
+Every output row is checked through size-independent properties (index range, strictly descending row indexes,
+idempotence of a second launch, per-query status, feature identities that do not need the oracle), and the oracle is
+run on an evenly spaced sample of the queries PLUS every query the fast kernel handed to the literal kernel."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_config(oracle, n_truth, n_queries, k, oracle_sample, seed=20260101):
+    import doppel_speller_amd as ds
+    from doppel_speller_amd import synth
+    w = synth.make_workload(n_truth, n_queries, seed=seed)
+    pipeline = ds.CandidatePipeline(w, k)
+    pipeline.step()
+    stats = pipeline.sync()
+    rows = pipeline.rows()
+    status = pipeline.index.status(n_queries)
+    assert stats["error_queries"] == 0 and set(np.unique(status)) <= {0, 1}
+    assert stats["dense_queries"] == int((status == 1).sum())
+    assert stats["dense_reasons"]["ties"] == 0            # ties are served by the fast kernel (duplicate ranks)
+    assert stats["dense_queries"] <= 0.002 * n_queries     # the literal kernel is the rare path
+
+    # ---- every row: range, strictly descending row indexes (match_maker.py:71 `[::-1][:k]`)
+    assert rows.shape == (n_queries, k) and rows.dtype == np.int32
+    assert rows.min() >= 0 and rows.max() < n_truth
+    assert (np.diff(rows.astype(np.int64), axis=1) < 0).all()
+    # a derived query finds the row it was derived from -- unless that row has k twins of larger index (the
+    # generator repeats short titles; match_maker.py:71 keeps the k largest row indexes of a tie)
+    derived = np.nonzero(w.actual_row >= 0)[0]
+    found = (rows[derived] == w.actual_row[derived, None]).any(axis=1)
+    assert found.mean() > 0.6
+
+    # ---- every pair: feature identities that need no oracle (feature_engineering.py:164-169), in chunks of 4M pairs
+    words_of_truth = ((w.t_enc == 1).sum(axis=1) + 1).astype(np.int64)          # feature_engineering.py:105
+    slots = np.arange(15)[None, :]
+    chunk = 4_000_000 // k * k
+    for first in range(0, n_queries * k, chunk):
+        features = pipeline.features(min(chunk, n_queries * k - first), first)
+        pair_t = rows.reshape(-1)[first:first + features.shape[0]]
+        pair_q = np.arange(first, first + features.shape[0], dtype=np.int64) // k
+        assert np.array_equal(features[:, 0], w.q_len[pair_q].astype(np.float32))
+        assert np.array_equal(features[:, 1], w.t_len[pair_t].astype(np.float32))
+        words_t = words_of_truth[pair_t]
+        assert np.array_equal(features[:, 3], words_t.astype(np.float32))
+        assert (features[:, 4] >= 0).all() and (features[:, 4] <= 100).all()
+        for block in (6, 21, 36, 51):                         # best ratios, word lengths, idf, ranks: NaN beyond the words
+            assert np.array_equal(np.isnan(features[:, block:block + 15]), slots >= np.minimum(words_t, 15)[:, None])
+        del features
+
+    # ---- idempotence: a second launch over the same resident inputs gives the same bytes
+    pipeline.enqueue_top_k()
+    pipeline.sync()
+    assert np.array_equal(pipeline.rows(), rows)
+
+    # ---- the oracle on a sample + on every literal-kernel query
+    sample = np.unique(np.concatenate((np.linspace(0, n_queries - 1, oracle_sample).astype(np.int64),
+                                       np.nonzero(status == 1)[0])))
+    counts = np.diff(w.q_rowptr)[sample]
+    starts = w.q_rowptr[sample]
+    flat = np.concatenate([w.q_cols[s:s + c] for s, c in zip(starts, counts)]) if sample.shape[0] else w.q_cols[:0]
+    sub_rowptr = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
+    expected = oracle.jaccard_topk(w.rowptr, w.truth_idx, w.idf32, w.sums32, sub_rowptr, flat, w.q_maxint[sample], k)
+    bad = np.nonzero((rows[sample] != expected).any(axis=1))[0]
+    assert bad.shape[0] == 0, (sample[bad][:10], rows[sample][bad[:2]], expected[bad[:2]])
+    check = sample[:min(sample.shape[0], 400)]
+    got = pipeline.features_of(check)
+    pq = np.repeat(check, k)
+    pt = rows[check].reshape(-1)
+    reference = oracle.construct_features(w.q_len[pq], w.t_len[pt], w.q_enc[pq], w.t_enc[pt], w.t_counts[pt], 1, n_truth)
+    assert np.array_equal(got.view(np.uint32), reference.view(np.uint32))
+    return stats
+
+
+def test_c2_full_size(oracle):
+    """BASELINE.json configs[1]: 100k synthetic queries x 500k truth titles, tri-gram vocabulary ~50k, top-10."""
+    stats = _check_config(oracle, 500_000, 100_000, 10, oracle_sample=2000)
+    assert stats["sparse_tiles"] > stats["dense_tiles"]
+
+
+def test_c3_full_size(oracle):
+    """BASELINE.json configs[2]: 1M queries x 5M truth titles, top-50 (175 score tiles, 50M pairs)."""
+    _check_config(oracle, 5_000_000, 1_000_000, 50, oracle_sample=200)

@@ -168,3 +168,29 @@ def test_library_is_tied_to_its_sources(monkeypatch):
     monkeypatch.setenv("DS_AUTO_REBUILD", "0")
     with pytest.raises(_lib.DoppelError, match="stale library is refused"):
         _lib.lib()
+
+
+def test_pair_list_restatement_against_a_pandas_transcription(oracle):
+    """oracle.remaining_pairs / select_matches (NumPy) against the reference's own pandas formulation of
+    predict.py:172-183 and :246-252 (groupby / transform(max) / duplicated), on random inputs with ties."""
+    import pandas as pd
+    rng = np.random.RandomState(4)
+    n, k = 300, 6
+    rows = rng.randint(0, 1000, (n, k)).astype(np.int32)
+    best = np.where(rng.rand(n) < 0.4, rng.randint(0, 1000, n), -1).astype(np.int32)
+    frame = pd.DataFrame({"test_index": np.repeat(np.arange(n), k), "match": rows.reshape(-1)})
+    matched_so_far = set(np.nonzero(best >= 0)[0].tolist())
+    remaining = frame.loc[~(frame["test_index"].isin(matched_so_far)), :]          # predict.py:183
+    pair_q, pair_t = oracle.remaining_pairs(best, rows)
+    assert np.array_equal(pair_q, remaining["test_index"].to_numpy()) and np.array_equal(pair_t, remaining["match"].to_numpy())
+    predictions = rng.choice(np.array([0.1, 0.5, 0.9, 0.93, 0.97], dtype=np.float32), pair_q.shape[0])
+    remaining = remaining.assign(prediction=predictions)
+    at_max = remaining.groupby(["test_index"])["prediction"].transform(max) == remaining["prediction"]   # :246-247
+    matches = remaining.loc[at_max, :]
+    matches = matches.loc[matches["prediction"] > np.float32(0.9), :]                                      # :249-250
+    duplicated = matches.loc[matches.duplicated(["test_index"]), "test_index"]                             # :158-161
+    matches = matches.loc[~(matches["test_index"].isin(duplicated)), :]
+    query, match = oracle.select_matches(pair_q, pair_t, predictions, k, 0.9)
+    expected = dict(zip(matches["test_index"], matches["match"]))
+    assert {int(q): int(m) for q, m in zip(query, match) if m >= 0} == expected
+    assert len(expected) > 10 and (match < 0).sum() > 10
