@@ -5,12 +5,13 @@
 // float64 in source order (:63).  The DP matrix is uint8 (:42): as long as L <= 255 no cell can wrap and the
 // identity is exact; beyond that the stores wrap modulo 256 and only a literal emulation reproduces the result.
 //
-// One wavefront (64 lanes) per (title, truth title) pair:
+// Half a wavefront (32 lanes) per (title, truth title) pair -- two pairs share every vector instruction, the kernel being
+// bound by instruction issue and most of a pair's work using ~20 lanes (one window start per lane):
 //   * LCS by the bit-parallel recurrence V' = (V + (V & M[c])) | (V & ~M[c]) over a 64-bit column vector (pattern =
 //     the shorter string, <= 64 chars; M[c] = match mask of the pattern for character code c, built in LDS with one
 //     ds_or per pattern character);
 //   * the word loop of :128-155 maps one window start per lane: every lane runs the recurrence for its window
-//     against the current truth word, then a wave max-reduction keeps the first best window (:147-149);
+//     against the current truth word, then a half-wave max-reduction keeps the first best window (:147-149);
 //   * pairs that do not fit (L > 255, pattern > 64 chars, character code >= 64) take the literal path: an
 //     anti-diagonal DP with uint8 wrap-around, three diagonals staged in LDS, 64 cells per step.
 // All strings, masks and the reconstructed title live in LDS; HBM traffic is the title bytes in and 264 B out.

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kForestThreads) void ds_forest_kernel(ForestArgs a)
         __syncthreads();
         if (static_cast<int>(threadIdx.x) < rows_here) {
             const float *row = staged + threadIdx.x * stride;
-            float margin = a.base_margin;
+            float margin = 0.f;  // xgboost: PredValue sums the leaves from zero, the base margin is added to that sum
             for (int32_t t = 0; t < a.n_trees; ++t) {
                 const int64_t root = a.tree_offsets[t];
                 int64_t node = root;
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(kForestThreads) void ds_forest_kernel(ForestArgs a)
                 }
                 margin = margin + a.threshold[node];
             }
+            margin = a.base_margin + margin;
             if (a.margins) a.margins[first + threadIdx.x] = margin;
             if (a.probabilities) a.probabilities[first + threadIdx.x] = 1.0f / (1.0f + expf(-margin));
         }

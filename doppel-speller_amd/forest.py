@@ -73,6 +73,41 @@ class ForestModel:
                     no=cat(no, np.int32), missing=cat(missing, np.int32),
                     tree_offsets=np.array(offsets, dtype=np.int64), base_margin=base_margin)
 
+    @staticmethod
+    def parse_xgboost_model_json(model, ntree_limit=None):
+        """`Booster.save_model('model.json')` (xgboost >= 1.0) -> the flat arrays.  Unlike the text dump, this format
+        carries every split condition and leaf value as the exact float32 the booster holds."""
+        if isinstance(model, (str, bytes)):
+            model = json.loads(model)
+        learner = model["learner"]
+        trees = learner["gradient_booster"]["model"]["trees"]
+        if ntree_limit:
+            trees = trees[:ntree_limit]
+        feature, threshold, yes, no, missing, offsets = [], [], [], [], [], [0]
+        for tree in trees:
+            left = np.asarray(tree["left_children"], dtype=np.int32)
+            right = np.asarray(tree["right_children"], dtype=np.int32)
+            leaf = left < 0
+            f = np.where(leaf, -1, np.asarray(tree["split_indices"], dtype=np.int32)).astype(np.int32)
+            t = np.asarray(tree["split_conditions"], dtype=np.float32)      # leaves: the leaf value
+            default_left = np.asarray(tree["default_left"], dtype=bool)
+            feature.append(f); threshold.append(t)
+            yes.append(np.where(leaf, 0, left)); no.append(np.where(leaf, 0, right))
+            missing.append(np.where(leaf, 0, np.where(default_left, left, right)))
+            offsets.append(offsets[-1] + left.shape[0])
+        cat = lambda parts, dtype: np.concatenate(parts).astype(dtype) if parts else np.zeros(0, dtype)
+        base_score = float(learner["learner_model_param"]["base_score"])
+        return dict(feature=cat(feature, np.int32), threshold=cat(threshold, np.float32), yes=cat(yes, np.int32),
+                    no=cat(no, np.int32), missing=cat(missing, np.int32),
+                    tree_offsets=np.array(offsets, dtype=np.int64),
+                    base_margin=math.log(base_score / (1.0 - base_score)))
+
+    @classmethod
+    def from_xgboost_model_json(cls, model, n_features, ntree_limit=None, device=0):
+        a = cls.parse_xgboost_model_json(model, ntree_limit)
+        return cls(a["feature"], a["threshold"], a["yes"], a["no"], a["missing"], a["tree_offsets"], n_features,
+                   a["base_margin"], device)
+
     @classmethod
     def from_xgboost_dump(cls, trees, n_features, ntree_limit=None, base_score=0.5, device=0):
         a = cls.parse_xgboost_dump(trees, ntree_limit, base_score)

@@ -1,9 +1,9 @@
 """transform_title (doppelspeller/common.py:20-47): the normalisation every title goes through before n-grams, words
-and encodings are derived from it.  `transform_title` is the reference's function restated; `transform_titles` is the
-batch form: the Unicode step (NFD + ASCII encoding) stays with Python's `unicodedata` and is skipped for ASCII titles,
-the byte work runs natively (`ds_transform_titles`, host code in libdoppel_amd.so)."""
+and encodings are derived from it.  `transform_titles` is the batch form: the Unicode step (NFD + ASCII encoding,
+common.py:25-26) stays with Python's `unicodedata` and is skipped for ASCII titles, the byte work (:26-38) runs natively
+(`ds_transform_titles`, host code in libdoppel_amd.so).  The line-by-line restatement of the reference function lives
+with the tests' CPU restatements, not in the product."""
 import ctypes
-import re
 import unicodedata
 
 import numpy as np
@@ -12,21 +12,11 @@ from . import _lib
 
 N_GRAMS = 3                                  # settings.py:15
 MAX_CHARACTERS_ALLOWED_IN_THE_TITLE = 255    # settings.py:68
-_SUBSTITUTE_REGEX = re.compile(r' +')        # common.py:16
-_KEEP_REGEX = re.compile(r'[a-zA-Z0-9\s]')   # common.py:17
 
 
 def transform_title(title):
-    """Transforms a title in to alpha-numeric-only (plus spaces) text (common.py:20-47, warnings not reproduced)."""
-    text = unicodedata.normalize('NFD', title)                                           # :25
-    text = text.encode('ascii', 'ignore').decode('utf-8').lower().replace('-', ' ')      # :26
-    text = ''.join(_KEEP_REGEX.findall(text))                                            # :28
-    text = _SUBSTITUTE_REGEX.sub(' ', text).strip()                                      # :30
-    number_of_characters = len(text)
-    text = text[:MAX_CHARACTERS_ALLOWED_IN_THE_TITLE].strip()                            # :32
-    if number_of_characters < N_GRAMS:
-        return text.rjust(N_GRAMS, '0')                                                  # :38
-    return text
+    """common.py:20-47 for one title (warnings not reproduced): the batch form below on a list of one."""
+    return transform_titles([title])[0]
 
 
 def transform_titles(titles):

@@ -413,13 +413,14 @@ void ds_oracle_close_ratios(const uint8_t *x_len, const uint8_t *y_len, const ui
  * PUBLISHED prediction rule of an xgboost `binary:logistic` booster on a dense float32 matrix with missing = NaN
  * (xgb.DMatrix(features), predict.py:229): per tree, from the root: a missing value follows the node's `missing`
  * child, otherwise value < split_condition follows `yes`, else `no`; the leaf values of the first n_trees trees
- * are added in tree order in float32 to the base margin; the prediction is 1 / (1 + exp(-margin)).  Parity unpinned
+ * are summed in tree order in float32 starting from zero and the base margin is added to that sum (xgboost's
+ * PredValue / PredLoopSpecalize); the prediction is 1 / (1 + exp(-margin)).  Parity unpinned
  * against the real library.  Node layout: feature < 0 marks a leaf whose value is in `threshold`. */
 float ds_oracle_forest_margin(const int32_t *feature, const float *threshold, const int32_t *yes, const int32_t *no,
                               const int32_t *missing, const int64_t *tree_offsets, int32_t n_trees, float base_margin,
                               const float *row)
 {
-    float margin = base_margin;
+    float margin = 0.f;  /* cpu_predictor PredValue: psum = 0, += leaf per tree; the caller's buffer holds base_margin */
     for (int32_t t = 0; t < n_trees; ++t) {
         int64_t node = tree_offsets[t];
         while (feature[node] >= 0) {
@@ -431,7 +432,7 @@ float ds_oracle_forest_margin(const int32_t *feature, const float *threshold, co
         }
         margin = margin + threshold[node];
     }
-    return margin;
+    return base_margin + margin;
 }
 
 void ds_oracle_forest_predict(const int32_t *feature, const float *threshold, const int32_t *yes, const int32_t *no,

@@ -206,3 +206,18 @@ def select_matches(pair_q, pair_t, predictions, k, threshold=0.9):
     where = holds.argmax(axis=1)
     match = np.where(single, pair_t[np.arange(pair_t.shape[0]), where], -1).astype(np.int32)
     return pair_q[:, 0].astype(np.int32), match
+
+
+def transform_title(title, n_grams=3, max_characters=255):
+    """common.py:20-47 restated line by line (warnings not reproduced); pinned by tests/golden/transform_title.json."""
+    import re
+    import unicodedata
+    text = unicodedata.normalize('NFD', title)                                           # :25
+    text = text.encode('ascii', 'ignore').decode('utf-8').lower().replace('-', ' ')      # :26
+    text = ''.join(re.findall(r'[a-zA-Z0-9\s]', text))                                   # :17, :28
+    text = re.sub(r' +', ' ', text).strip()                                              # :16, :30
+    number_of_characters = len(text)
+    text = text[:max_characters].strip()                                                 # :32
+    if number_of_characters < n_grams:
+        return text.rjust(n_grams, '0')                                                  # :38
+    return text
