@@ -354,13 +354,21 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.k;
     const int64_t ptr_stride = static_cast<int64_t>(a.n_tiles) + 1;
-    const uint2 *quads = reinterpret_cast<const uint2 *>(a.postings);
-    const uint2 *sums_quads = reinterpret_cast<const uint2 *>(a.posting_sums);
-    // The kernel arguments arrive as one 16-register tuple; under register pressure the allocator spills and reloads
-    // the WHOLE tuple (16 v_readlane in front of every posting load).  Opaque copies give the two pointers of the hot
-    // loops scalar register pairs of their own.
-    asm volatile("" : "+s"(quads));
-    asm volatile("" : "+s"(sums_quads));
+    // The kernel arguments arrive as 16-register tuples; under register pressure the allocator spills and reloads a
+    // WHOLE tuple (16 v_readlane in front of every posting load that needs one pointer of it).  The two pointers of the
+    // hot loops are therefore rebuilt from scalar copies of their halves -- registers of their own, outside any tuple --
+    // and keep the global address space (plain global_load, not flat_load).
+    typedef const unsigned long long __attribute__((address_space(1))) *GlobalQuads;
+    auto load_quad = [](GlobalQuads base, uint32_t at) {
+        const unsigned long long bits = base[at];
+        return make_uint2(static_cast<uint32_t>(bits), static_cast<uint32_t>(bits >> 32));
+    };
+    auto own_registers = [](const void *pointer) {
+        const uint64_t bits = reinterpret_cast<uint64_t>(pointer);
+        const uint32_t lo = uniform(static_cast<uint32_t>(bits)), hi = uniform(static_cast<uint32_t>(bits >> 32));
+        return reinterpret_cast<GlobalQuads>((static_cast<uint64_t>(hi) << 32) | lo);
+    };
+    const GlobalQuads quads = own_registers(a.postings), sums_quads = own_registers(a.posting_sums);
 
     for (int i = tid * 4; i < kScoreWords; i += kThreads * 4)
         *reinterpret_cast<uint4 *>(&iscores[i]) = make_uint4(0u, 0u, 0u, 0u);
@@ -686,8 +694,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     value[u] = 0;
                     if (at < n_items) locate(at, first, end, value[u]);
                     live[u] = first < end && DS_OK_INDEX(3, first, a.n_quads);
-                    quad[u] = live[u] ? quads[first] : make_uint2(kSentinel * 0x10001u, kSentinel * 0x10001u);
-                    if (single_round && live[u]) quad_info[u] = sums_quads[first];
+                    quad[u] = live[u] ? load_quad(quads, first) : make_uint2(kSentinel * 0x10001u, kSentinel * 0x10001u);
+                    if (single_round && live[u]) quad_info[u] = load_quad(sums_quads, first);
                 }
 #pragma unroll
                 for (int u = 0; u < kRound; ++u) {
@@ -726,9 +734,12 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                         // (extraction inside the same branch would wait for every atomic separately)
                         uint32_t before[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            before[e] = 0u;
-                            if (live[u] && local[e] < kTile && !DS_DEBUG_BIT(16))
+                        for (int e = 0; e < 4; ++e) before[e] = 0u;
+                        if (live[u] && !DS_DEBUG_BIT(16)) {
+                            // ONE exec-masked region per quad (idle lanes stay off the LDS); the padding entries of a
+                            // list's last quad take from the trash word instead of being branched around one by one
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
                                 before[e] = atomicAnd(&iscores[local[e] >> 1], ~(0xffffu << ((local[e] & 1u) << 4)));
                         }
 #pragma unroll
@@ -739,7 +750,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                         for (int e = 0; e < 4; ++e) {
                             const uint32_t have = taken[e] + mass16[info[e] & 0xffu];
                             const uint32_t need = max(gate_fixed, static_cast<uint32_t>(need16[info[e] >> 8]));
-                            pass[e] = (taken[e] != 0u) & (have >= need);
+                            // what a padding entry took from the trash word is not a row
+                            pass[e] = (local[e] < static_cast<uint32_t>(kTile)) & (taken[e] != 0u) & (have >= need);
                         }
 #ifdef DS_DIAGNOSTICS
                         if (a.phase != nullptr) {  // selectivity of a row-independent gate (tuning experiment)
@@ -768,8 +780,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                             uint32_t first = 0, end = 0, value = 0;
                             if (at < n_items) locate(at, first, end, value);
                             live[u] = first < end && DS_OK_INDEX(3, first, a.n_quads);
-                            quad[u] = live[u] ? quads[first] : make_uint2(kSentinel * 0x10001u, kSentinel * 0x10001u);
-                            if (live[u]) quad_info[u] = sums_quads[first];
+                            quad[u] = live[u] ? load_quad(quads, first) : make_uint2(kSentinel * 0x10001u, kSentinel * 0x10001u);
+                            if (live[u]) quad_info[u] = load_quad(sums_quads, first);
                         }
                         collect();
                     }
