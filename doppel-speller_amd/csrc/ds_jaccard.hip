@@ -88,7 +88,7 @@ constexpr int kOffBitIdf = kOffSigBit + kMaxQueryColumns * 4;
 constexpr int kOffFixed = kOffBitIdf + kSignatureBits * 4;
 constexpr int kOffTotal = kOffFixed + kMaxQueryColumns * 4;
 constexpr int kOffMassTable = kOffTotal + kMaxQueryColumns * 4;
-constexpr int kOffPtr = kOffMassTable + 256 * 4;
+constexpr int kOffPtr = kOffMassTable + 256 * 6;  // need32[256] then mass16[256]
 constexpr int kOffHist = kOffMassTable;  // the radix histogram shares the mass table: every selection is followed by
                                          // a rebuild of the table before its next use
 constexpr int kOffCtrl = kOffPtr + kMaxQueryColumns * (kPtrTiles + 1) * 4;
@@ -344,9 +344,11 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
     uint32_t *fixed = reinterpret_cast<uint32_t *>(lds + kOffFixed);  // idf[j] in the query's fixed-point scale
     uint32_t *iscores = reinterpret_cast<uint32_t *>(lds);  // score tile: 16-bit fixed-point sums, row r in half (r & 1) of word r >> 1
     uint32_t *col_total = reinterpret_cast<uint32_t *>(lds + kOffTotal);  // quads of column j over all tiles
-    // [0..255] mass16, [256..511] need16: the integer tables of the collect sweep's row test (rebuilt after a selection)
-    uint16_t *mass16 = reinterpret_cast<uint16_t *>(lds + kOffMassTable);
-    uint16_t *need16 = mass16 + 256;
+    // need32[256] (by 8-bit sums code) and mass16[256] (by signature bits 0..7): the integer tables of the collect
+    // sweep's row test, rebuilt after a selection.  need32[255] -- the code of the lists' padding entries, which take
+    // whatever the trash word holds -- is beyond every score.
+    uint32_t *need32 = reinterpret_cast<uint32_t *>(lds + kOffMassTable);
+    uint16_t *mass16 = reinterpret_cast<uint16_t *>(lds + kOffMassTable + 256 * 4);
     uint32_t *ptr_cache = reinterpret_cast<uint32_t *>(lds + kOffPtr);  // [column][span + 1], kMaxQueryColumns * (kPtrTiles + 1) words
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + kOffHist);
     volatile int32_t *ctrl = reinterpret_cast<volatile int32_t *>(lds + kOffCtrl);
@@ -513,7 +515,9 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     // a row with k or more twins (same column set, same sums32) of larger index can never be among the
                     // k largest row indexes of match_maker.py:71, and the k-th largest value does not need it either
                     const bool shadowed = static_cast<int>(a.dup_rank[t]) >= k;
-                    if (!shadowed && may_qualify(raw, sums, bounds)) {
+                    // a zero score reaches this point only through the collect sweep's rounding slack (a second
+                    // posting of a row whose score another lane took): never a candidate
+                    if (!shadowed && raw > 0.f && may_qualify(raw, sums, bounds)) {
                         const float full = complete_score(raw, signature, skipped, bit_idf);
                         ok = candidate_key(full, sums, bounds, key);
                     }
@@ -574,8 +578,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     const float value = round_up_positive((rest + some) * (1.0 + 3.814697265625e-06) + 1e-30);
                     const float mass = value < bounds.mass ? value : bounds.mass;
                     // The collect sweep tests rows in the integer domain of the fixed-point scores:
-                    //   score + mass16[signature bits 0..7] >= max(tile gate, need16[8-bit sums code])
-                    // mass16 is rounded up and need16 down by more than the float test's own roundings, so the rows
+                    //   score + mass16[signature bits 0..7] >= max(tile gate, need32[8-bit sums code])
+                    // mass16 is rounded up and need32 down by more than the float test's own roundings, so the rows
                     // that pass are a superset of those of `passes` (no conversions, no float decoding per posting).
                     const double unit = static_cast<double>(from_fixed);
                     const double mass_units = static_cast<double>(mass) / unit + 2.0;
@@ -583,7 +587,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     const double need_units = static_cast<double>(bounds.coef) *
                                                   (static_cast<double>(decode_sums8(tid)) + static_cast<double>(maxint32)) /
                                                   unit - 2.0;
-                    need16[tid] = static_cast<uint16_t>(need_units < 0.0 ? 0.0 : (need_units < 65535.0 ? need_units : 65535.0));
+                    need32[tid] = tid == 255 ? 0x7fffffffu
+                                             : static_cast<uint32_t>(need_units < 0.0 ? 0.0 : (need_units < 65535.0 ? need_units : 65535.0));
                 }
             }
             const bool sparse = tight && sparse_mode;
@@ -695,7 +700,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                     if (at < n_items) locate(at, first, end, value[u]);
                     live[u] = first < end && DS_OK_INDEX(3, first, a.n_quads);
                     quad[u] = live[u] ? load_quad(quads, first) : make_uint2(kSentinel * 0x10001u, kSentinel * 0x10001u);
-                    if (single_round && live[u]) quad_info[u] = load_quad(sums_quads, first);
+                    if (single_round)  // idle lanes carry the padding code 255: their (zero) scores never pass the collect sweep's test
+                        quad_info[u] = live[u] ? load_quad(sums_quads, first) : make_uint2(0xff00ff00u, 0xff00ff00u);
                 }
 #pragma unroll
                 for (int u = 0; u < kRound; ++u) {
@@ -718,9 +724,14 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 // Cheap integer pre-test on the taken fixed-point scores: a row can only pass `s + mass >= pre` if its
                 // score reaches (pre - mass) in fixed-point units (rounded down, minus slack: a superset of the float
                 // test).  Most quads have no such row and skip the per-row decoding and table lookups altogether.
+                // A row whose score is zero here (another posting of the row took it first) has nothing but its mass16:
+                // the gate is kept at or above the largest mass16 so that such a row fails `have >= need` without a
+                // test of its own.  (It can still pass when it owns every skipped column AND the gate had to be
+                // raised, i.e. pre - mass is within the tables' 4 units of rounding slack; the refinement rejects it.)
                 const uint32_t gate_fixed = [&]() {  // the tile's row-independent bound `here.pre`, rounded down
                     const double units = static_cast<double>(here.pre) / static_cast<double>(from_fixed) - 2.0;
-                    return units > 0.0 ? static_cast<uint32_t>(units) : 0u;
+                    const uint32_t gate = units > 0.0 ? static_cast<uint32_t>(units) : 0u;
+                    return max(gate, static_cast<uint32_t>(mass16[255]));
                 }();
                 auto collect = [&]() {
 #pragma unroll
@@ -749,9 +760,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const uint32_t have = taken[e] + mass16[info[e] & 0xffu];
-                            const uint32_t need = max(gate_fixed, static_cast<uint32_t>(need16[info[e] >> 8]));
-                            // what a padding entry took from the trash word is not a row
-                            pass[e] = (local[e] < static_cast<uint32_t>(kTile)) & (taken[e] != 0u) & (have >= need);
+                            const uint32_t need = max(gate_fixed, need32[info[e] >> 8]);
+                            pass[e] = have >= need;  // padding entries carry code 255: never; zero scores: see the gate
                         }
 #ifdef DS_DIAGNOSTICS
                         if (a.phase != nullptr) {  // selectivity of a row-independent gate (tuning experiment)
@@ -781,7 +791,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                             if (at < n_items) locate(at, first, end, value);
                             live[u] = first < end && DS_OK_INDEX(3, first, a.n_quads);
                             quad[u] = live[u] ? load_quad(quads, first) : make_uint2(kSentinel * 0x10001u, kSentinel * 0x10001u);
-                            if (live[u]) quad_info[u] = load_quad(sums_quads, first);
+                            quad_info[u] = live[u] ? load_quad(sums_quads, first) : make_uint2(0xff00ff00u, 0xff00ff00u);
                         }
                         collect();
                     }
