@@ -39,9 +39,6 @@ constexpr int kPtrTiles = DS_PTR_TILES;                 // tiles whose list poin
 constexpr int kSignatureBits = 128;          // densest columns whose membership is kept as a per-row bit (uint4)
 constexpr int kSignatureWords = kSignatureBits / 32;
 constexpr int kControlWords = 32;            // int32 control block in HBM (queue heads, counters)
-constexpr int kSlowSlotsMax = 256;           // concurrent queries of the exact dense kernel (scratch = slots*N*8 B)
-constexpr int kSlowSlotsMin = 16;
-constexpr int64_t kSlowScratchBytes = int64_t(8) << 30;  // scratch budget that sizes the number of slots
 
 // 8-bit lower bound of a positive float: 4 exponent bits (2^-3 .. 2^12) and 4 mantissa bits, truncated.
 // decode(encode(x)) <= x for every x >= 0; code 0 decodes to 0.
@@ -66,7 +63,7 @@ inline uint64_t mix64(uint64_t x)
     return x;
 }
 
-enum QueryStatus : int32_t { kQueryDone = 0, kQuerySlow = 1, kQueryErrorTopN = 2, kQueryErrorArg = 3 };
+enum QueryStatus : int32_t { kQueryDone = 0, kQuerySlow = 1, kQueryErrorTopN = 2, kQueryErrorArg = 3, kQueryErrorTies = 4, kQuerySlowFew = 5 };
 
 void set_error(const char *format, ...);
 void duplicate_ranks(const int64_t *rowptr, const int32_t *truth_idx, const float *sums32, int64_t V, int64_t N,
@@ -135,9 +132,6 @@ struct ds_index {
     ds::DeviceBuffer<uint32_t> signature;  // [n_truth][4] bit g = row is in the posting list of the g-th densest column
     ds::DeviceBuffer<int8_t> sig_column;   // [n_columns] signature bit of a column, -1 for all but the 128 densest
     ds::DeviceBuffer<uint16_t> dup_rank;   // [n_truth] rows with the same column set and sums32 bits but a larger index (saturating)
-    ds::DeviceBuffer<double> slow_scratch; // [kSlowSlots][n_truth] float64 jaccard rows of the exact dense kernel
-    ds::DeviceBuffer<uint32_t> slow_keys;  // [kSlowSlots][slow_keys_cap] compacted float32 keys (radix passes 3 and 4)
-    int64_t slow_keys_cap = 0;
     bool literal_only = false;             // idf32 / sums32 hold negative or non-finite values: the bounds of the fast kernel
                                            // do not apply, every query takes the literal kernel
     ds::DeviceBuffer<int32_t> control;     // [16] work-queue head, slow-list length, error count, counters
@@ -146,7 +140,6 @@ struct ds_index {
     ds::DeviceBuffer<unsigned long long> phase;  // diagnostic phase timers (DS_PHASE_TIMERS=1)
     hipStream_t stream = nullptr;          // used by the host-pointer entry points
     int compute_units = 256;
-    int slow_slots = 16;
     hipEvent_t event_begin = nullptr, event_fast = nullptr, event_dense = nullptr;  // per-kernel timing of the last call
     bool attributes_set = false;
     bool count_bytes = false;              // launch the instantiation of the fast kernel that counts its requested bytes

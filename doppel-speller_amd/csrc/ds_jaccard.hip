@@ -49,9 +49,6 @@ struct JaccardArgs {
     int32_t *status;
     int32_t *control;
     int32_t *slow_list;
-    double *slow_scratch;
-    uint32_t *slow_keys;        // [slots][slow_keys_cap] float32 keys of the rows that share the k-th value's top byte
-    int64_t slow_keys_cap;
     unsigned long long *phase;  // nullable: per-phase shader-clock sums (diagnostics, DS_PHASE_TIMERS=1)
     int64_t n_truth;
     int64_t n_columns;
@@ -1075,7 +1072,9 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
 
         if (!slow) __syncthreads();
         int m = slow ? 0 : uniform(static_cast<int>(ctrl[kLCount]));
-        if (!slow && m < k) { slow = true; reason = 5; }  // fewer than k positive rows: literal path decides
+        // Fewer than k candidates: fewer than k rows have a positive score at all (nothing is pruned before k candidates
+        // exist).  The literal kernel answers it without sweeping anything (the answer is the k largest row indexes).
+        if (!slow && m < k) { slow = true; reason = 5; }
         if (!slow) {
             // final tightening so that only k + near-ties + margin survivors are evaluated exactly
             if (m > k) {
@@ -1201,7 +1200,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             DS_STAMP(5);
         } else {
             if (tid == 0) {
-                a.status[q] = kQuerySlow;
+                a.status[q] = reason == 5 ? kQuerySlowFew : kQuerySlow;
                 a.slow_list[atomicAdd(&a.control[kCtlSlowCount], 1)] = static_cast<int32_t>(q);
                 if (reason >= 0) atomicAdd(&a.control[kCtlReason + reason], 1);
                 if constexpr (kCountBytes) *requested += 8ull * query_units;
@@ -1230,40 +1229,108 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
 }
 
 // ---- the literal algorithm for the queries the fast kernel hands over ------------------------------------------------
+// fast_jaccard exactly as the reference runs it (ordered float32 accumulation per row, float64 finalise,
+// match_maker.py:45-50), tile by tile FROM THE LAST TILE DOWN, and fast_arg_top_k (:53-71) as a streaming selection
+// that needs no N-vector in HBM:
+//   the rows that can still matter are kept in an LDS buffer of (float64 jaccard, row).  With T_run = float32(k-th
+//   largest value seen so far) - 1e-6 (a lower bound of the final threshold, which only grows):
+//     (a) a row below T_run is below the final threshold: dropped for good;
+//     (b) a row r that has k rows of LARGER index with a value >= its own can be dropped too: if r qualifies at the end
+//         so do those k rows, and :71 returns the k largest indexes; the k-th largest value does not need r either
+//         (its k dominators keep it in place).
+//   Rows arrive tile by tile, 1024 at a time; when the next 1024 might not fit, the buffer is compacted with (a) and, if
+//   that is not enough, (b).  At the end the k-th largest float32 value of the buffer IS the reference's heap minimum.
 constexpr int kDenseScoreFloats = kTile + 64;  // float32 score tile + trash slot
-constexpr int kDenseChunk = 256;  // query columns whose (list begin, list end, idf) are staged in LDS at a time
-constexpr int kDenseLdsBytes = kDenseScoreFloats * 4 + 256 * 4 + 64 + (kDenseThreads / 64) * 4 + 64 + kDenseChunk * 12;
+constexpr int kDenseChunk = 256;   // query columns whose (list begin, list end, idf) are staged in LDS at a time
+constexpr int kDenseBuffer = 3072; // rows kept per query: value float64 + row int32 = 36 KiB
+constexpr int kDenseOffHist = kDenseScoreFloats * 4;
+constexpr int kDenseOffCtrl = kDenseOffHist + 256 * 4;
+constexpr int kDenseOffStage = kDenseOffCtrl + 128;
+constexpr int kDenseOffValue = kDenseOffStage + kDenseChunk * 12;
+constexpr int kDenseOffRow = kDenseOffValue + kDenseBuffer * 8;
+constexpr int kDenseLdsBytes = kDenseOffRow + kDenseBuffer * 4;
+static_assert(kDenseLdsBytes <= 160 * 1024 && kDenseOffValue % 8 == 0, "LDS budget of the literal kernel");
+constexpr int kDenseKeep = (kDenseBuffer + kDenseThreads - 1) / kDenseThreads;
+enum { kDCount = 0, kDDigit, kDRemain, kDQuery, kDKept };
+
+__device__ __forceinline__ uint32_t dense_key(double v)  // the float32 the reference's heap stores (match_maker.py:65)
+{
+    return v > 0.0 ? __float_as_uint(static_cast<float>(v)) : 0u;
+}
+
+// k-th largest float32 key of the m buffered values (m >= k); every thread of the workgroup calls it
+__device__ uint32_t dense_select_kth(const double *value, int m, int k, uint32_t *hist, volatile int32_t *ctrl)
+{
+    const int tid = threadIdx.x;
+    uint32_t prefix = 0, mask = 0;
+    int remaining = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < m; i += kDenseThreads) {
+            const uint32_t key = dense_key(value[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cumulative = 0, digit = 0;
+            for (int d = 255; d >= 0; --d) {
+                const int c = static_cast<int>(hist[d]);
+                if (cumulative + c >= remaining) { digit = d; break; }
+                cumulative += c;
+            }
+            ctrl[kDDigit] = digit;
+            ctrl[kDRemain] = remaining - cumulative;
+        }
+        __syncthreads();
+        prefix |= static_cast<uint32_t>(ctrl[kDDigit]) << shift;
+        mask |= 255u << shift;
+        remaining = ctrl[kDRemain];
+    }
+    return prefix;
+}
 
 __global__ __launch_bounds__(kDenseThreads) void ds_jaccard_dense_kernel(JaccardArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     float *scores = reinterpret_cast<float *>(lds);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(lds + kDenseScoreFloats * 4);
-    volatile int32_t *ctrl = reinterpret_cast<volatile int32_t *>(lds + kDenseScoreFloats * 4 + 1024);
-    int32_t *wave_counts = const_cast<int32_t *>(ctrl) + 16;
-    uint32_t *stage_begin = reinterpret_cast<uint32_t *>(lds + kDenseScoreFloats * 4 + 1024 + 64 + (kDenseThreads / 64) * 4 + 64);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds + kDenseOffHist);
+    volatile int32_t *ctrl = reinterpret_cast<volatile int32_t *>(lds + kDenseOffCtrl);
+    uint32_t *stage_begin = reinterpret_cast<uint32_t *>(lds + kDenseOffStage);
     uint32_t *stage_end = stage_begin + kDenseChunk;
     float *stage_value = reinterpret_cast<float *>(stage_end + kDenseChunk);
+    double *value = reinterpret_cast<double *>(lds + kDenseOffValue);
+    int32_t *row = reinterpret_cast<int32_t *>(lds + kDenseOffRow);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int k = a.k;
     const int64_t n_truth = a.n_truth;
     const int64_t ptr_stride = static_cast<int64_t>(a.n_tiles) + 1;
-    double *jaccard = a.slow_scratch + static_cast<int64_t>(blockIdx.x) * n_truth;
-    uint32_t *compact = a.slow_keys + static_cast<int64_t>(blockIdx.x) * a.slow_keys_cap;
     const int n_slow = a.control[kCtlSlowCount];
 
     for (;;) {
-        if (tid == 0) ctrl[kLQuery] = atomicAdd(&a.control[kCtlSlowQueue], 1);
+        if (tid == 0) {
+            ctrl[kDQuery] = atomicAdd(&a.control[kCtlSlowQueue], 1);
+            ctrl[kDCount] = 0;
+        }
         __syncthreads();
-        const int item = ctrl[kLQuery];
+        const int item = ctrl[kDQuery];
         __syncthreads();
-        if (item >= n_slow) break;
+        if (item >= n_slow) break;  // exit condition reached by every wave: the queue head only grows
         const int64_t q = a.slow_list[item];
         const int64_t qbase = a.q_rowptr[q];
         const int64_t n = a.q_rowptr[q + 1] - qbase;
         const double maxint = a.q_maxint[q];
 
+        if (a.status[q] == kQuerySlowFew) {
+            // The fast kernel found fewer than k rows with a positive score (and its assumptions hold: no negative
+            // value exists): the heap of match_maker.py:60-67 keeps a zero, the threshold is -1e-6, EVERY row qualifies
+            // and :71 returns the k largest row indexes.
+            for (int j = tid; j < k; j += kDenseThreads) a.out_rows[q * k + j] = static_cast<int32_t>(n_truth - 1 - j);
+            if (tid == 0) a.status[q] = kQuerySlow;
+            __syncthreads();
+            continue;
+        }
         bool bad = false;
         for (int64_t j = tid; j < n; j += kDenseThreads) {
             const int32_t column = a.q_cols[qbase + j];
@@ -1278,10 +1345,62 @@ __global__ __launch_bounds__(kDenseThreads) void ds_jaccard_dense_kernel(Jaccard
             continue;
         }
 
-        // fast_jaccard, tile by tile: ordered float32 accumulation (a barrier between two columns), float64 finalise.
-        // The histogram of the first radix pass (top 8 bits of the float32 value) is taken while finalising.
-        if (tid < 256) hist[tid] = 0;
-        for (int b = 0; b < a.n_tiles; ++b) {
+        // Compaction of the buffer: T_run from the k-th largest float32 value, rule (a), then rule (b) if the buffer is
+        // still more than a quarter full.
+        double t_run = -1.0;  // no threshold yet: every positive value is kept
+        bool failed = false;
+        auto compact = [&]() {
+            __syncthreads();
+            const int m = ctrl[kDCount];
+            if (m >= k) {
+                const uint32_t kth = dense_select_kth(value, m, k, hist, ctrl);
+                const double tightened = static_cast<double>(__uint_as_float(kth)) - static_cast<double>(1e-6f);  // :70
+                if (tightened > t_run) t_run = tightened;
+            }
+            double keep_value[kDenseKeep];
+            int32_t keep_row[kDenseKeep];
+#pragma unroll
+            for (int r = 0; r < kDenseKeep; ++r) {
+                const int i = tid + r * kDenseThreads;
+                keep_value[r] = i < m ? value[i] : -1.0;
+                keep_row[r] = i < m ? row[i] : -1;
+                if (!(keep_value[r] >= t_run)) keep_row[r] = -1;                                   // rule (a)
+            }
+            if (tid == 0) ctrl[kDKept] = 0;  // survivors of rule (a)
+            __syncthreads();
+            int mine = 0;
+#pragma unroll
+            for (int r = 0; r < kDenseKeep; ++r) mine += keep_row[r] >= 0;
+            if (mine) atomicAdd(const_cast<int32_t *>(&ctrl[kDKept]), mine);
+            __syncthreads();
+            if (ctrl[kDKept] > kDenseBuffer / 4) {                                                  // rule (b)
+#pragma unroll
+                for (int r = 0; r < kDenseKeep; ++r) {
+                    if (keep_row[r] < 0) continue;
+                    int dominators = 0;
+                    for (int j = 0; j < m; ++j) {  // the buffer itself is still intact: read-only here
+                        const int32_t other = row[j];
+                        const double v = value[j];
+                        dominators += (other > keep_row[r]) & (v >= keep_value[r]);
+                    }
+                    if (dominators >= k) keep_row[r] = -1;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) ctrl[kDCount] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kDenseKeep; ++r) {
+                if (keep_row[r] < 0) continue;
+                const int slot = atomicAdd(const_cast<int32_t *>(&ctrl[kDCount]), 1);
+                value[slot] = keep_value[r];
+                row[slot] = keep_row[r];
+            }
+            __syncthreads();
+        };
+
+        // scores[] of tile b: ordered float32 accumulation, a barrier between two columns (match_maker.py:46-48)
+        auto scatter_tile = [&](int b) {
             for (int i = tid; i < kDenseScoreFloats; i += kDenseThreads) scores[i] = 0.f;
             __syncthreads();
             for (int64_t j0 = 0; j0 < n; j0 += kDenseChunk) {
@@ -1309,13 +1428,13 @@ __global__ __launch_bounds__(kDenseThreads) void ds_jaccard_dense_kernel(Jaccard
                 };
                 fetch(0);
                 for (int j = 0; j < width; ++j) {
-                    const float value = stage_value[j];
+                    const float idf = stage_value[j];
                     const uint32_t begin = stage_begin[j], end = stage_end[j];
                     uint32_t local[4] = {next[0], next[1], next[2], next[3]};
                     if (j + 1 < width) fetch(j + 1);
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (local[u] < kTile) scores[local[u]] = scores[local[u]] + value;  // each row at most once per list
+                        if (local[u] < kTile) scores[local[u]] = scores[local[u]] + idf;  // each row at most once per list
                     for (uint32_t i0 = begin + tid + 4 * kDenseThreads; i0 < end; i0 += 4 * kDenseThreads) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -1324,155 +1443,115 @@ __global__ __launch_bounds__(kDenseThreads) void ds_jaccard_dense_kernel(Jaccard
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            if (local[u] < kTile) scores[local[u]] = scores[local[u]] + value;
+                            if (local[u] < kTile) scores[local[u]] = scores[local[u]] + idf;
                     }
                     __syncthreads();
                 }
             }
+        };
+
+        for (int b = a.n_tiles - 1; b >= 0 && !failed; --b) {
+            scatter_tile(b);
+            // finalise the tile (match_maker.py:50), from its last rows down, and keep what can still matter.  Before a
+            // chunk of rows is looked at the buffer has room for all of it: one barrier per chunk decides, uniformly,
+            // whether to compact first.
             const int64_t tile_base = static_cast<int64_t>(b) * kTile;
-            for (int i0 = tid; i0 < kTile && tile_base + i0 < n_truth; i0 += 4 * kDenseThreads) {
-                float sums[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u * kDenseThreads;
-                    sums[u] = (i < kTile && tile_base + i < n_truth) ? a.sums32[tile_base + i] : 1.f;
+            const int rows_here = static_cast<int>(n_truth - tile_base < kTile ? n_truth - tile_base : kTile);
+            for (int top = rows_here; top > 0 && !failed; top -= kDenseThreads) {
+                if (__syncthreads_or(ctrl[kDCount] > kDenseBuffer - kDenseThreads)) {
+                    compact();
+                    if (ctrl[kDCount] > kDenseBuffer - kDenseThreads) failed = true;  // (a) and (b) cannot make room
+                    __syncthreads();
+                    if (failed) break;
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u * kDenseThreads;
-                    if (!(i < kTile && tile_base + i < n_truth)) continue;
+                const int i = top - 1 - tid;
+                double v = 0.0;
+                if (i >= 0) {
                     const double s = static_cast<double>(scores[i]);
-                    const double v = s / (static_cast<double>(sums[u]) + (maxint - s));  // match_maker.py:50
-                    jaccard[tile_base + i] = v;
-                    const uint32_t key = v > 0.0 ? __float_as_uint(static_cast<float>(v)) : 0u;
-                    if (key != 0u) atomicAdd(&hist[key >> 24], 1u);
+                    v = s / (static_cast<double>(a.sums32[tile_base + i]) + (maxint - s));
                 }
-            }
-            __syncthreads();
-        }
-        __threadfence_block();
-
-        // fast_arg_top_k: the float32 heap ends as the k largest float32(value > 0) padded with zeros
-        uint32_t prefix = 0, mask = 0;
-        int remaining = k;
-        bool fewer = false;
-        // Pass 1 (top byte) was taken while finalising.  Pass 2 reads the whole row once more and, besides its own
-        // histogram, compacts the float32 keys that share the k-th value's top byte; passes 3 and 4 then read only
-        // that list (a fraction of N) -- unless it does not fit, in which case they scan the row again.
-        bool use_compact = false;
-        int compact_count = 0;
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            if (shift != 24) {
-                if (tid < 256) hist[tid] = 0;
-                if (tid == 0 && shift == 16) ctrl[kLCount] = 0;
-                __syncthreads();
-                if (use_compact) {
-                    for (int i0 = tid; i0 < compact_count; i0 += 8 * kDenseThreads) {
-                        uint32_t key[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int i = i0 + u * kDenseThreads;
-                            key[u] = i < compact_count ? compact[i] : 0u;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (key[u] != 0u && (key[u] & mask) == prefix) atomicAdd(&hist[(key[u] >> shift) & 255u], 1u);
-                    }
-                } else {
-                    // eight independent loads in flight per thread: the pass is bound by latency otherwise
-                    for (int64_t base = 0; base < n_truth; base += 8 * kDenseThreads) {  // uniform trip count
-                        const int64_t t0 = base + tid;
-                        double v[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int64_t t = t0 + u * kDenseThreads;
-                            v[u] = t < n_truth ? jaccard[t] : 0.0;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const uint32_t key = v[u] > 0.0 ? __float_as_uint(static_cast<float>(v[u])) : 0u;
-                            const bool match = key != 0u && (key & mask) == prefix;
-                            if (match) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-                            if (shift == 16) {  // wave-aggregated append to the compact list (all lanes take part)
-                                const unsigned long long votes = __ballot(match);
-                                if (votes != 0) {
-                                    const int leader = __ffsll(votes) - 1;
-                                    int base = 0;
-                                    if (lane == leader) base = atomicAdd(const_cast<int32_t *>(&ctrl[kLCount]), __popcll(votes));
-                                    base = __shfl(base, leader);
-                                    const int64_t slot = base + __popcll(votes & ((1ull << lane) - 1ull));
-                                    if (match && slot < a.slow_keys_cap) compact[slot] = key;
-                                }
-                            }
-                        }
+                const bool keep = i >= 0 && v > 0.0 && v >= t_run;
+                const unsigned long long votes = __ballot(keep);
+                if (votes != 0) {
+                    const int leader = __ffsll(votes) - 1;
+                    int base = 0;
+                    if (lane == leader) base = atomicAdd(const_cast<int32_t *>(&ctrl[kDCount]), __popcll(votes));
+                    base = __shfl(base, leader);
+                    if (keep) {
+                        const int slot = base + __popcll(votes & ((1ull << lane) - 1ull));
+                        value[slot] = v;
+                        row[slot] = static_cast<int32_t>(tile_base + i);
                     }
                 }
-                __syncthreads();
-                if (shift == 16) {
-                    compact_count = ctrl[kLCount];
-                    use_compact = compact_count <= a.slow_keys_cap;
-                    __threadfence_block();
-                }
             }
-            if (tid == 0) {
-                int cumulative = 0, digit = -1;
-                for (int d = 255; d >= 0; --d) {
-                    const int c = static_cast<int>(hist[d]);
-                    if (cumulative + c >= remaining) { digit = d; break; }
-                    cumulative += c;
-                }
-                ctrl[kLDigit] = digit;
-                ctrl[kLRemain] = remaining - cumulative;
-            }
-            __syncthreads();
-            if (ctrl[kLDigit] < 0) { fewer = true; break; }  // fewer than k positive float32 values: k-th = 0
-            prefix |= static_cast<uint32_t>(ctrl[kLDigit]) << shift;
-            mask |= 255u << shift;
-            remaining = ctrl[kLRemain];
             __syncthreads();
         }
-        const float kth32 = fewer ? 0.f : __uint_as_float(prefix);
-        const double threshold = static_cast<double>(kth32) - static_cast<double>(1e-6f);
-
-        // (array >= threshold).nonzero()[0][::-1][:k]
-        // Rounds of 8 * kDenseThreads rows from the top; thread `tid` owns eight consecutive rows (all eight loads in
-        // flight), a block-wide prefix of the per-thread counts gives every qualifying row its descending position.
-        int found = 0;
-        constexpr int kPer = 8;
-        for (int64_t top = n_truth - 1; top >= 0 && found < k; top -= kPer * kDenseThreads) {
-            const int64_t first = top - static_cast<int64_t>(tid) * kPer;  // this thread: rows first, first - 1, ...
-            double v[kPer];
-#pragma unroll
-            for (int u = 0; u < kPer; ++u) v[u] = first - u >= 0 ? jaccard[first - u] : -1.0;
-            uint32_t pass_bits = 0;
-#pragma unroll
-            for (int u = 0; u < kPer; ++u) pass_bits |= (first - u >= 0 && v[u] >= threshold) ? 1u << u : 0u;
-            const int mine = __popc(pass_bits);
-            const int inclusive = static_cast<int>(wave_inclusive_scan(static_cast<uint32_t>(mine), lane));
-            if (lane == 63) wave_counts[wave] = inclusive;
-            __syncthreads();
-            int before = 0, total = 0;
-            for (int w = 0; w < kDenseThreads / 64; ++w) {
-                const int c = wave_counts[w];
-                before += w < wave ? c : 0;
-                total += c;
-            }
-            int slot = found + before + inclusive - mine;
-#pragma unroll
-            for (int u = 0; u < kPer; ++u) {
-                if ((pass_bits >> u) & 1u) {
-                    if (slot < k) a.out_rows[q * k + slot] = static_cast<int32_t>(first - u);
-                    ++slot;
-                }
-            }
-            found += total;
-            __syncthreads();
-        }
-        if (found < k) {
-            for (int j = found + tid; j < k; j += kDenseThreads) a.out_rows[q * k + j] = -1;
+        if (failed) {
+            for (int j = tid; j < k; j += kDenseThreads) a.out_rows[q * k + j] = -1;
             if (tid == 0) {
-                a.status[q] = kQueryErrorTopN;
+                a.status[q] = kQueryErrorTies;
                 atomicAdd(&a.control[kCtlErrors], 1);
+            }
+            __syncthreads();
+            continue;
+        }
+        __syncthreads();
+        const int m = ctrl[kDCount];
+        // fast_arg_top_k: the float32 heap ends as the k largest float32(value > 0) padded with zeros (:60-67)
+        double threshold = -static_cast<double>(1e-6f);           // fewer than k positive values: heap minimum 0
+        if (m >= k) threshold = static_cast<double>(__uint_as_float(dense_select_kth(value, m, k, hist, ctrl))) -
+                                static_cast<double>(1e-6f);       // :70
+        if (threshold <= 0.0 && !a.literal_only && maxint > 0.0) {
+            // every row qualifies, zeros included (with idf >= 0, sums >= a row's own total and maxint > 0 every
+            // denominator is positive and no value negative): (array >= threshold).nonzero()[0][::-1][:k] = the k
+            // largest indexes
+            for (int j = tid; j < k; j += kDenseThreads) a.out_rows[q * k + j] = static_cast<int32_t>(n_truth - 1 - j);
+        } else if (threshold <= 0.0) {
+            // Negative idf values or a non-positive max_intersection_possible (both possible through the C ABI only)
+            // make negative or undefined jaccards: the rows at or above a non-positive threshold are the zero rows and
+            // more -- nothing the buffer holds.  Second sweep from the last
+            // tile down, taking qualifying rows in descending index order until k are found (:71).
+            int found = 0;
+            int32_t *wave_counts = reinterpret_cast<int32_t *>(hist);
+            for (int b = a.n_tiles - 1; b >= 0 && found < k; --b) {
+                scatter_tile(b);
+                const int64_t tile_base = static_cast<int64_t>(b) * kTile;
+                const int rows_here = static_cast<int>(n_truth - tile_base < kTile ? n_truth - tile_base : kTile);
+                for (int top = rows_here; top > 0 && found < k; top -= kDenseThreads) {
+                    const int i = top - 1 - tid;  // thread 0 holds the largest row of the chunk
+                    bool qualifies = false;
+                    if (i >= 0) {
+                        const double s = static_cast<double>(scores[i]);
+                        qualifies = s / (static_cast<double>(a.sums32[tile_base + i]) + (maxint - s)) >= threshold;
+                    }
+                    const unsigned long long votes = __ballot(qualifies);
+                    if (lane == 0) wave_counts[tid >> 6] = __popcll(votes);
+                    __syncthreads();
+                    int before = 0, total = 0;
+                    for (int w = 0; w < kDenseThreads / 64; ++w) {
+                        before += w < (tid >> 6) ? wave_counts[w] : 0;
+                        total += wave_counts[w];
+                    }
+                    const int position = found + before + __popcll(votes & ((1ull << lane) - 1ull));
+                    if (qualifies && position < k) a.out_rows[q * k + position] = static_cast<int32_t>(tile_base + i);
+                    found += total;
+                    __syncthreads();
+                }
+            }
+            if (found < k) {  // match_maker.py:188-189
+                for (int j = found + tid; j < k; j += kDenseThreads) a.out_rows[q * k + j] = -1;
+                if (tid == 0) {
+                    a.status[q] = kQueryErrorTopN;
+                    atomicAdd(&a.control[kCtlErrors], 1);
+                }
+            }
+        } else {
+            for (int i = tid; i < m; i += kDenseThreads) {
+                if (!(value[i] >= threshold)) continue;           // :71
+                const int32_t t = row[i];
+                int above = 0;
+                for (int j = 0; j < m; ++j) above += (value[j] >= threshold) & (row[j] > t);
+                if (above < k) a.out_rows[q * k + above] = t;
             }
         }
         __syncthreads();
@@ -1526,9 +1605,6 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
     args.status = index->status.ptr;
     args.control = index->control.ptr;
     args.slow_list = index->slow_list.ptr;
-    args.slow_scratch = index->slow_scratch.ptr;
-    args.slow_keys = index->slow_keys.ptr;
-    args.slow_keys_cap = index->slow_keys_cap;
     args.phase = nullptr;
     if (const char *timers = getenv("DS_PHASE_TIMERS"); timers != nullptr && timers[0] == '1') {
         if (index->phase.count == 0 && index->phase.allocate(16) != DS_OK) return DS_E_HIP;
@@ -1561,7 +1637,7 @@ static int launch(ds_index *index, const int64_t *d_q_rowptr, const int32_t *d_q
         hipLaunchKernelGGL(ds_jaccard_topk_kernel<false>, dim3(grid), dim3(kThreads), kFastLdsBytes, stream, args);
     DS_HIP(hipGetLastError());
     DS_HIP(hipEventRecord(index->event_fast, stream));
-    hipLaunchKernelGGL(ds_jaccard_dense_kernel, dim3(index->slow_slots), dim3(kDenseThreads), kDenseLdsBytes, stream, args);
+    hipLaunchKernelGGL(ds_jaccard_dense_kernel, dim3(index->compute_units), dim3(kDenseThreads), kDenseLdsBytes, stream, args);
     DS_HIP(hipGetLastError());
     DS_HIP(hipEventRecord(index->event_dense, stream));
     return DS_OK;
@@ -1621,6 +1697,11 @@ static int collect(ds_index *index, hipStream_t stream, int64_t stats[32])
             if (status[q] == kQueryErrorTopN) {
                 set_error("top_matches.shape[0] != self.top_n (query %zu)", q);
                 return DS_E_TOP_N;
+            }
+            if (status[q] == kQueryErrorTies) {
+                set_error("ds_jaccard_topk: query %zu has more than %d rows within 1e-6 of its k-th largest jaccard that "
+                          "are neither twins nor dominated (literal kernel buffer)", q, 3072);
+                return DS_E_INTERNAL;
             }
             if (status[q] == kQueryErrorArg) {
                 set_error("ds_jaccard_topk: query %zu has a column index outside [0, V)", q);

@@ -270,11 +270,6 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     if (status == DS_OK) status = index->signature.upload(signature.data(), signature.size());
     if (status == DS_OK) status = index->sig_column.upload(sig_column.data(), sig_column.size());
     if (status == DS_OK) status = index->dup_rank.upload(dup_rank.data(), dup_rank.size());
-    index->slow_slots = static_cast<int>(std::max<int64_t>(
-        ds::kSlowSlotsMin, std::min<int64_t>(ds::kSlowSlotsMax, ds::kSlowScratchBytes / (8 * N))));
-    if (status == DS_OK) status = index->slow_scratch.allocate(static_cast<size_t>(index->slow_slots) * N);
-    index->slow_keys_cap = std::min<int64_t>(N, int64_t(1) << 20);
-    if (status == DS_OK) status = index->slow_keys.allocate(static_cast<size_t>(index->slow_slots) * index->slow_keys_cap);
     if (status == DS_OK) status = index->control.allocate(ds::kControlWords);
     if (status == DS_OK && (hipStreamCreate(&index->stream) != hipSuccess ||
                             hipEventCreate(&index->event_begin) != hipSuccess ||
@@ -325,8 +320,7 @@ int ds_index_info(const ds_index *index, int64_t info[8])
     info[3] = ds::kTile;
     info[4] = index->n_tiles;
     info[5] = static_cast<int64_t>(index->col_ptr.bytes() + index->postings.bytes() + index->posting_sums.bytes() + index->idf32.bytes() +
-                                   index->sums32.bytes() + index->signature.bytes() + index->sig_column.bytes() + index->dup_rank.bytes() +
-                                   index->slow_scratch.bytes() + index->slow_keys.bytes());
+                                   index->sums32.bytes() + index->signature.bytes() + index->sig_column.bytes() + index->dup_rank.bytes());
     info[6] = index->n_quads * 4;
     info[7] = 0;
     return DS_OK;

@@ -307,6 +307,50 @@ def test_values_outside_the_bounds_assumptions_take_the_literal_kernel(oracle):
     assert stats["dense_queries"] == 24 and stats["error_queries"] == 0
 
 
+@pytest.mark.parametrize("k", [1, 10, 100, 512])
+def test_literal_kernel_with_massive_ties(oracle, k):
+    """The literal kernel's streaming selection (no N-vector): 6000 twin rows tied at the top and an index that forces
+    every query onto the literal path (negative idf values).  Buffer overflow on the first tile, compaction by the
+    running threshold and by the k-dominators rule, tiles finalised again -- the answers equal the oracle's."""
+    problem = _tie_problem(np.random.RandomState(15), 90000, 6000)
+    problem["idf32"] = problem["idf32"].copy()
+    problem["idf32"][5::11] *= -1.0
+    index = _check(oracle, problem, k)
+    stats = index.sync()
+    assert stats["dense_queries"] == 40 and stats["error_queries"] == 0
+
+
+def test_literal_kernel_many_equal_values_that_are_not_twins(oracle):
+    """4000 rows with the same jaccard for different reasons (not twins), literal path: rule (b) keeps the k largest
+    indexes of the tie, the threshold semantics of match_maker.py:70-71 decide the rest."""
+    rng = np.random.RandomState(18)
+    problem = _random_problem(rng, 60000, 2000, 8)
+    n_columns = problem["rowptr"].shape[0] - 1
+    lists = [problem["truth_idx"][problem["rowptr"][g]:problem["rowptr"][g + 1]] for g in range(n_columns)]
+    tied = np.arange(4000, dtype=np.int32) * 13 + 5          # spread over three tiles
+    lists = [l[~np.isin(l, tied)] for l in lists]
+    for g in (10, 11, 12):
+        lists[g] = np.sort(np.concatenate((tied, lists[g])))
+    lists[20], lists[21] = tied[::2], tied[1::2]
+    problem["rowptr"] = np.concatenate(([0], np.cumsum([len(l) for l in lists]))).astype(np.int64)
+    problem["truth_idx"] = np.concatenate(lists).astype(np.int32)
+    idf32 = problem["idf32"].copy()
+    idf32[21] = idf32[20]
+    idf32[30::17] *= -1.0                                      # literal-only index
+    problem["idf32"] = idf32
+    sums = problem["sums32"].copy()
+    sums[tied] = np.float32(idf32[10]) + np.float32(idf32[11]) + np.float32(idf32[12]) + np.float32(idf32[20])
+    problem["sums32"] = sums
+    q_cols = [np.array([10, 11, 12], dtype=np.int32)] * 4 + [np.array([10, 11, 12, 20], dtype=np.int32)] * 4
+    problem["q_rowptr"] = np.concatenate(([0], np.cumsum([len(c) for c in q_cols]))).astype(np.int64)
+    problem["q_cols"] = np.concatenate(q_cols).astype(np.int32)
+    idf64 = idf32.astype(np.float64)
+    problem["q_maxint"] = np.array([float(np.sum(idf64[c])) for c in q_cols])
+    for k in (10, 50):
+        index = _check(oracle, problem, k)
+        assert index.sync()["dense_queries"] == 8
+
+
 def test_inconsistent_sums_take_the_literal_kernel(oracle):
     """sums32 smaller than a row's own idf total (again only possible through the C ABI) is detected at index build."""
     rng = np.random.RandomState(78)
