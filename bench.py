@@ -23,10 +23,10 @@ the max over ranks go through a TCP rendezvous.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
   roofline      ds_jaccard_topk_kernel against the HBM roofline: achieved = bytes the kernel REQUESTS from global
-                memory per launch (counted by the kernel: postings, per-posting info, sums32, signatures, list
-                pointers, exact-stage probes) / its average launch duration (HIP events on the launch stream);
-                `traffic` = FETCH_SIZE + WRITE_SIZE of profiles/pmc_latest.json when that file was measured on this
-                build and workload; `bound_model` = the kernel's shares of VALU issue, LDS and HBM time from the same
+                memory per launch (counted by a second instantiation of the kernel in one untimed launch: postings,
+                per-posting info, sums32 of dense scans, list pointers) / its average launch duration (HIP events
+                on the launch stream); `traffic` = 2 * FETCH_SIZE + WRITE_SIZE of profiles/pmc_latest.json when that
+                file was measured on this build and workload; `bound_model` = the kernel's shares of VALU issue, LDS and HBM time from the same
                 counters; `speedup_over_reference_hbm_floor` = the bytes the REFERENCE's algorithm would read
                  / launch duration / 8 TB/s -- above 1 because the kernel skips most of them.
   cpu_baseline  the oracle (C restatement of the reference, OpenMP) timed on a bounded sample of the same workload
@@ -300,8 +300,10 @@ def main():
                     "algorithmic_bytes_per_launch": requested, "avg_launch_ms": mean_topk,
                     "bytes_per_query": requested / max(1, per_gpu),
                     "note": "algorithmic bytes = what THIS kernel requests from global memory per launch (2-byte "
-                            "postings of the traversed lists + per-posting info, sums32, signatures, list pointers, "
-                            "exact-stage probes), counted by the kernel; `traffic` = PMC FETCH_SIZE + WRITE_SIZE"}
+                            "postings of the traversed lists + per-posting row info, sums32 of the dense scans, list "
+                            "pointers, per-column setup), counted by a second instantiation of the kernel in one extra "
+                            "untimed launch; `traffic` = 2 * FETCH_SIZE + WRITE_SIZE of profiles/pmc_latest.json "
+                            "(FETCH_SIZE counts half of coalesced streams on gfx950) when measured on this build"}
         pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as handle:
