@@ -61,6 +61,20 @@ def log(*args):
     print(*args, file=sys.stderr, flush=True)
 
 
+def heartbeat(label, every=60.0):
+    """A progress line on stderr every minute while a long host-side phase runs (the workload of C5 takes minutes to
+    generate; a silent process looks hung to whoever watches it).  Returns a function that stops it."""
+    import threading
+    done = threading.Event()
+    started = time.perf_counter()
+
+    def beat():
+        while not done.wait(every):
+            log(f"... {label}: {time.perf_counter() - started:.0f}s")
+    threading.Thread(target=beat, daemon=True).start()
+    return done.set
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as handle:
@@ -179,11 +193,15 @@ def main():
 
     # ---- synthetic workload: truth replicated (same seed), queries distinct per rank
     t0 = time.perf_counter()
+    stop = heartbeat("generating the workload") if rank == 0 else (lambda: None)
     workload = synth.make_workload(truth, per_gpu, seed=args.seed, query_seed=args.seed + 1000 * (rank + 1))
+    stop()
     if rank == 0:
         log(f"workload: {time.perf_counter() - t0:.1f}s  {synth.workload_statistics(workload)}")
     t0 = time.perf_counter()
+    stop = heartbeat("index build + upload") if rank == 0 else (lambda: None)
     pipeline = ds.CandidatePipeline(workload, k, device=device)
+    stop()
     if rank == 0:
         log(f"upload + index build: {time.perf_counter() - t0:.1f}s  {pipeline.index.info()}")
     stream_handle = None

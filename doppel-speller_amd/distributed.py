@@ -63,45 +63,82 @@ class Rendezvous:
     """World-wide host-side exchange for one process per GPU: rank 0 listens on (address, port), every other rank
     connects.  All operations are collective and must be called by every rank in the same order."""
 
-    def __init__(self, rank, world_size, address="127.0.0.1", port=29533, timeout=600.0):
+    _MAGIC = b"DSRV1"
+
+    def __init__(self, rank, world_size, address="127.0.0.1", port=29533, timeout=600.0, port_file=None):
+        """port: where rank 0 listens.  With `port_file`, rank 0 falls back to any free port when `port` is taken and
+        publishes the port it got in that file (written atomically); the other ranks read it before every attempt."""
         self.rank, self.world_size = rank, world_size
         self.peers = {}
         self.server = None
         if world_size == 1:
             return
         if rank == 0:
+            if port_file and os.path.exists(port_file):
+                os.unlink(port_file)  # a previous job's
             self.server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             self.server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            self.server.bind((address, port))
+            try:
+                self.server.bind((address, port))
+            except OSError:
+                if not port_file:
+                    raise
+                self.server.bind((address, 0))
+            if port_file:
+                with open(port_file + ".tmp", "w") as handle:
+                    handle.write(str(self.server.getsockname()[1]))
+                os.replace(port_file + ".tmp", port_file)
             self.server.listen(world_size)
             self.server.settimeout(timeout)
             while len(self.peers) < world_size - 1:
                 connection, _ = self.server.accept()
                 connection.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 connection.settimeout(timeout)
-                (peer,) = struct.unpack("<i", _receive(connection))
-                self.peers[peer] = connection
+                try:
+                    hello = _receive(connection)
+                except (ConnectionError, OSError, struct.error):
+                    connection.close()
+                    continue
+                if len(hello) != len(self._MAGIC) + 4 or not hello.startswith(self._MAGIC):
+                    connection.close()  # not one of ours
+                    continue
+                _send(connection, self._MAGIC)
+                self.peers[struct.unpack("<i", hello[len(self._MAGIC):])[0]] = connection
         else:
             deadline = time.time() + timeout
             while True:
+                connection = None
                 try:
-                    connection = socket.create_connection((address, port), timeout=5.0)
-                    break
-                except OSError:
-                    if time.time() > deadline:
-                        raise
-                    time.sleep(0.05)
+                    target = port
+                    if port_file and os.path.exists(port_file):
+                        with open(port_file) as handle:
+                            target = int(handle.read().strip() or port)
+                    connection = socket.create_connection((address, target), timeout=5.0)
+                    connection.settimeout(10.0)
+                    _send(connection, self._MAGIC + struct.pack("<i", rank))
+                    if _receive(connection) == self._MAGIC:
+                        break
+                    connection.close()
+                except (OSError, ValueError, ConnectionError, struct.error):
+                    if connection is not None:
+                        connection.close()
+                if time.time() > deadline:
+                    raise TimeoutError(f"rank {rank}: no rendezvous with rank 0 at {address}:{port}")
+                time.sleep(0.05)
             connection.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             connection.settimeout(timeout)
-            _send(connection, struct.pack("<i", rank))
             self.peers[0] = connection
 
     @classmethod
     def from_environment(cls, port_offset=1):
         """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as `torch.distributed.run` (or bench.py's own launcher) export
-        them; the launcher's store owns MASTER_PORT itself, so the star listens `port_offset` above it."""
+        them.  The launcher's store owns MASTER_PORT itself, so the star listens `port_offset` above it -- or, when
+        that port is taken, wherever rank 0 finds room: the port is published in a file named after MASTER_PORT."""
+        import tempfile
+        master_port = int(os.environ.get("MASTER_PORT", "29533"))
+        port_file = os.path.join(tempfile.gettempdir(), f"ds_rendezvous_{os.getuid()}_{master_port}.port")
         return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
-                   os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29533")) + port_offset)
+                   os.environ.get("MASTER_ADDR", "127.0.0.1"), master_port + port_offset, port_file=port_file)
 
     def all_gather_bytes(self, payload):
         """Every rank's payload, in rank order, on every rank."""

@@ -89,3 +89,34 @@ def test_gather_matches_single_process(tmp_path, world, n_queries):
     expected = oracle.jaccard_topk(w.rowptr, w.truth_idx, w.idf32, w.sums32, w.q_rowptr, w.q_cols, w.q_maxint, 10)
     for rank in range(world):   # an all-gather: every rank holds all rows, in query order
         assert np.array_equal(np.load(f"{result}.{rank}.npy"), expected)
+
+
+def _env_worker(rank, world, master_port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(master_port))
+    from doppel_speller_amd.distributed import Rendezvous
+    rendezvous = Rendezvous.from_environment()
+    parts = rendezvous.all_gather_bytes(bytes([rank]) * 3)
+    rendezvous.barrier()
+    with open(f"{out_path}.{rank}", "wb") as handle:
+        handle.write(b"".join(parts))
+    rendezvous.close()
+
+
+def test_rendezvous_from_environment_when_the_preferred_port_is_taken(tmp_path):
+    """MASTER_PORT + 1 is occupied by somebody else: rank 0 listens elsewhere and publishes the port in a file."""
+    with socket.socket() as blocker:
+        blocker.bind(("127.0.0.1", 0))
+        blocker.listen(1)
+        master_port = blocker.getsockname()[1] - 1
+        context = multiprocessing.get_context("spawn")
+        out = str(tmp_path / "parts")
+        ranks = [context.Process(target=_env_worker, args=(r, 3, master_port, out)) for r in range(3)]
+        for process in ranks:
+            process.start()
+        for process in ranks:
+            process.join(120)
+            assert process.exitcode == 0
+    for rank in range(3):
+        with open(f"{out}.{rank}", "rb") as handle:
+            assert handle.read() == b"\x00\x00\x00\x01\x01\x01\x02\x02\x02"
