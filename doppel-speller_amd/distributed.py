@@ -223,6 +223,23 @@ def _load_rccl():
     raise _lib.DoppelError("librccl.so not found (set DS_RCCL_LIBRARY)")
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on the PROCESS's stdout when a communicator is created; a caller whose stdout is
+    a protocol (bench.py: one JSON line) must not see it.  File descriptor 1 points at stderr while this is active."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 class RcclCommunicator:
     """One RCCL communicator over the ranks of the rendezvous (one process per GPU, device = LOCAL_RANK).
 
@@ -237,14 +254,17 @@ class RcclCommunicator:
         _lib.check(_lib.lib().ds_stream_sync(None, device), "select device")  # hipSetDevice(device) for RCCL
         unique = _NcclUniqueId()
         if self.rank == 0:
-            self._check(self.rccl.ncclGetUniqueId(ctypes.byref(unique)), "ncclGetUniqueId")
+            with _StdoutToStderr():
+                status = self.rccl.ncclGetUniqueId(ctypes.byref(unique))
+            self._check(status, "ncclGetUniqueId")
         raw = rendezvous.broadcast_bytes(ctypes.string_at(ctypes.byref(unique), 128) if self.rank == 0 else None)
         if len(raw) != 128:
             raise _lib.DoppelError("rendezvous delivered a malformed RCCL unique id")
         ctypes.memmove(ctypes.byref(unique), raw, 128)
         self.comm = ctypes.c_void_p()
-        self._check(self.rccl.ncclCommInitRank(ctypes.byref(self.comm), self.world_size, unique, self.rank),
-                    "ncclCommInitRank")
+        with _StdoutToStderr():
+            status = self.rccl.ncclCommInitRank(ctypes.byref(self.comm), self.world_size, unique, self.rank)
+        self._check(status, "ncclCommInitRank")
 
     def _check(self, status, what):
         if status != 0:

@@ -33,6 +33,21 @@ def test_rccl_single_rank_gather_on_device(oracle):
     _lib.check(_lib.lib().ds_stream_destroy(stream, 0), "stream")
 
 
+def test_bench_with_rccl_prints_one_json_line():
+    """One rank, RCCL communicator (DS_BENCH_FORCE_DIST=1): stdout carries the JSON line and nothing else -- RCCL's
+    version banner goes to stderr."""
+    env = dict(os.environ, DS_BENCH_FORCE_DIST="1")
+    env.pop("WORLD_SIZE", None)
+    result = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--queries", "3000", "--truth", "60000",
+                             "--k", "10", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--check", "32"],
+                            env=env, capture_output=True, text=True, timeout=600)
+    assert result.returncode == 0, result.stderr[-3000:]
+    lines = [line for line in result.stdout.splitlines() if line.strip()]
+    assert len(lines) == 1, result.stdout[:2000]
+    line = json.loads(lines[0])
+    assert line["rccl_ranks"] == 1 and line["verified_queries"] == 32 and "ncclAllGather" in line["collective"]
+
+
 def test_bench_spawns_its_own_ranks():
     """`bench.py --gpus 2` without a launcher starts two fresh rank processes (both on the box's only GPU here, hence
     the host communicator) and rank 0 prints one JSON line for the whole job."""
