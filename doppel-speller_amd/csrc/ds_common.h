@@ -21,7 +21,7 @@ namespace ds {
 #define DS_TILE_ROWS 28672
 #endif
 #ifndef DS_CANDIDATES
-#define DS_CANDIDATES 1728
+#define DS_CANDIDATES 1600
 #endif
 #ifndef DS_PTR_TILES
 #define DS_PTR_TILES 3

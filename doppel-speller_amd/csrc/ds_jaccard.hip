@@ -88,7 +88,9 @@ constexpr int kOffMassTable = kOffTotal + kMaxQueryColumns * 4;
 constexpr int kOffPtr = kOffMassTable + 256 * 6;  // need32[256] then mass16[256]
 constexpr int kOffHist = kOffMassTable;  // the radix histogram shares the mass table: every selection is followed by
                                          // a rebuild of the table before its next use
-constexpr int kOffCtrl = kOffPtr + kMaxQueryColumns * (kPtrTiles + 1) * 4;
+constexpr int kOffQuadPrefix = kOffPtr + kMaxQueryColumns * (kPtrTiles + 1) * 4;  // per tile: quads before column j
+constexpr int kOffQuadBase = kOffQuadPrefix + kMaxQueryColumns * 4;               // per tile: first quad of column j - prefix
+constexpr int kOffCtrl = kOffQuadBase + kMaxQueryColumns * 4;
 constexpr int kFastLdsBytes = kOffCtrl + 128;
 static_assert((kFastLdsBytes + 256) * kWorkgroupsPerCu <= 160 * 1024, "LDS budget of one CU exceeded");
 static_assert(kCandidates * 16 <= 32768 && 32768 + kCandidates * 8 <= kTile * 2, "exact-stage scratch fits the tile");
@@ -97,7 +99,7 @@ constexpr int kKeep = (kCandidates + kThreads - 1) / kThreads;  // candidate ent
 constexpr int kSelectTrigger = kCandidates - kSelectSlack;
 constexpr int kWaves = kThreads / 64;
 #ifndef DS_ROUND
-#define DS_ROUND 4
+#define DS_ROUND 3
 #endif
 #ifndef DS_SCAN_BATCH
 #define DS_SCAN_BATCH 1
@@ -347,6 +349,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
     uint32_t *need32 = reinterpret_cast<uint32_t *>(lds + kOffMassTable);
     uint16_t *mass16 = reinterpret_cast<uint16_t *>(lds + kOffMassTable + 256 * 4);
     uint32_t *ptr_cache = reinterpret_cast<uint32_t *>(lds + kOffPtr);  // [column][span + 1], kMaxQueryColumns * (kPtrTiles + 1) words
+    uint32_t *quad_prefix = reinterpret_cast<uint32_t *>(lds + kOffQuadPrefix);
+    uint32_t *quad_base = reinterpret_cast<uint32_t *>(lds + kOffQuadBase);
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + kOffHist);
     volatile int32_t *ctrl = reinterpret_cast<volatile int32_t *>(lds + kOffCtrl);
 
@@ -426,6 +430,7 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
             __syncthreads();
             continue;
         }
+        if (tid >= 64 && tid < kMaxQueryColumns) quad_prefix[tid] = 0xffffffffu;  // columns 64..127: see the item map
         // ascending-IDF order of the query's columns and the IDF mass of every prefix of that order
         if (tid < n) {
             const float mine = idf[tid];
@@ -589,61 +594,53 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
                 }
             }
             const bool sparse = tight && sparse_mode;
-            // ---- work items of this tile: (essential column, chunk of 64 quads).  Every wave computes the same
-            // exclusive prefix of the per-column item counts in registers (lane j: columns j and j + 64), so that no
-            // barrier and no LDS table is needed; item `at` belongs to the last column whose prefix is <= at.
-            uint32_t list_first[2], list_quads[2], item_before[2];
-            // fixed-point IDF of columns `lane` and `lane + 64`: read by v_readlane in `locate` (an LDS read there would
-            // sit, with its wait, in front of every item's global load)
-            const uint32_t fixed_lo = fixed[lane], fixed_hi = fixed[lane + 64];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int j = lane + 64 * h;
-                uint32_t begin = 0, end = 0;
-                if (j < n && rank[j] >= non_essential) {
-                    begin = ptr_cache[j * (span + 1) + bt];
-                    end = ptr_cache[j * (span + 1) + bt + 1];
-                }
-                list_first[h] = begin;
-                list_quads[h] = end - begin;
-            }
-            int n_items;
+            // ---- work items of this tile.  The essential columns' posting quads of the tile form ONE sequence (column after
+            // column); an item is 64 consecutive quads of it, so every lane of an item has a quad to work on whatever
+            // the lengths of the single lists (items of one list each were 76 % full on C2).  Every wave computes the
+            // same exclusive prefix of the lists' quad counts (lane j: columns j and j + 64, DPP scan) and writes it to
+            // LDS -- all eight waves write the same values, a wave only ever reads what its own lanes wrote -- and a
+            // lane finds the column of its quad by a branch-free binary search there: no ballots, no v_readlane, no
+            // scalar instructions per item.
+            uint32_t total_quads;
             {
-                const uint32_t count0 = (list_quads[0] + 63u) >> 6, count1 = (list_quads[1] + 63u) >> 6;
-                const uint32_t scan0 = wave_inclusive_scan(count0, lane);
-                const uint32_t total0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(scan0), 63));
-                uint32_t scan1 = 0, total1 = 0;
+                uint32_t quads_of[2] = {0u, 0u}, begin_of[2] = {0u, 0u};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = lane + 64 * h;
+                    if (j < n && rank[j] >= non_essential) {
+                        begin_of[h] = ptr_cache[j * (span + 1) + bt];
+                        quads_of[h] = ptr_cache[j * (span + 1) + bt + 1] - begin_of[h];
+                    }
+                }
+                const uint32_t scan0 = wave_inclusive_scan(quads_of[0], lane);
+                total_quads = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(scan0), 63));
+                const uint32_t before0 = scan0 - quads_of[0];
+                quad_prefix[lane] = lane < n ? before0 : 0xffffffffu;  // columns beyond the query's: never found
+                quad_base[lane] = begin_of[0] - before0;
                 if (n > 64) {
-                    scan1 = wave_inclusive_scan(count1, lane);
-                    total1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(scan1), 63));
+                    const uint32_t scan1 = wave_inclusive_scan(quads_of[1], lane);
+                    const uint32_t before1 = total_quads + scan1 - quads_of[1];
+                    total_quads += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(scan1), 63));
+                    quad_prefix[lane + 64] = lane + 64 < n ? before1 : 0xffffffffu;
+                    quad_base[lane + 64] = begin_of[1] - before1;
                 }
-                item_before[0] = scan0 - count0;
-                item_before[1] = total0 + scan1 - count1;
-                n_items = static_cast<int>(total0 + total1);
             }
-            // (first quad of this lane, end of the list, fixed-point IDF) of work item `at`
-            auto locate = [&](int at, uint32_t &first, uint32_t &end, uint32_t &value) {
-                const uint32_t want = static_cast<uint32_t>(at);
-                const int before = __popcll(__ballot(item_before[0] <= want)) + __popcll(__ballot(item_before[1] <= want));
-                const int j = before - 1, l = j & 63;
-                uint32_t begin, quads_in_list, prefix;
-                if (j < 64) {
-                    begin = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(list_first[0]), l));
-                    quads_in_list = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(list_quads[0]), l));
-                    prefix = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(item_before[0]), l));
-                } else {
-                    begin = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(list_first[1]), l));
-                    quads_in_list = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(list_quads[1]), l));
-                    prefix = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(item_before[1]), l));
+            const int n_items = static_cast<int>((total_quads + 63u) >> 6);
+            // (this lane's quad, fixed-point IDF of its column) of work item `at`; false beyond the last quad
+            auto locate = [&](int at, uint32_t &first, uint32_t &value) {
+                const uint32_t g = static_cast<uint32_t>(at) * 64u + lane;
+                uint32_t c = 0;
+#pragma unroll
+                for (uint32_t bit = kMaxQueryColumns / 2; bit > 0; bit >>= 1) {  // largest c with quad_prefix[c] <= g
+                    const uint32_t t = c + bit;
+                    c = quad_prefix[t] <= g ? t : c;
                 }
-                first = begin + (want - prefix) * 64u + lane;
-                end = begin + quads_in_list;
-                value = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j < 64 ? fixed_lo : fixed_hi), l));
+                first = quad_base[c] + g;
+                value = fixed[c];
+                return g < total_quads;
             };
             if constexpr (kCountBytes) {  // posting bytes of this tile: 8 per quad and sweep, 8 more for the collect sweep's row info
-                const uint32_t scanned = wave_inclusive_scan(list_quads[0] + list_quads[1], lane);
-                const uint32_t tile_quads = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(scanned), 63));
-                count_units(tile_quads * (sparse ? (n_items <= DS_ROUND * kWaves ? 2u : 3u) : 1u));
+                count_units(total_quads * (sparse ? (n_items <= DS_ROUND * kWaves ? 2u : 3u) : 1u));
             }
             DS_STAMP(1);
 
@@ -692,10 +689,9 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
 #pragma unroll
                 for (int u = 0; u < kRound; ++u) {
                     const int at = wave + (round + u) * kWaves;
-                    uint32_t first = 0, end = 0;
+                    uint32_t first = 0;
                     value[u] = 0;
-                    if (at < n_items) locate(at, first, end, value[u]);
-                    live[u] = first < end && DS_OK_INDEX(3, first, a.n_quads);
+                    live[u] = at < n_items && locate(at, first, value[u]) && DS_OK_INDEX(3, first, a.n_quads);
                     quad[u] = live[u] ? load_quad(quads, first) : make_uint2(kSentinel * 0x10001u, kSentinel * 0x10001u);
                     if (single_round)  // idle lanes carry the padding code 255: their (zero) scores never pass the collect sweep's test
                         quad_info[u] = live[u] ? load_quad(sums_quads, first) : make_uint2(0xff00ff00u, 0xff00ff00u);
@@ -784,9 +780,8 @@ __global__ __launch_bounds__(kThreads, kWorkgroupsPerCu * kThreads / 256) void d
 #pragma unroll
                         for (int u = 0; u < kRound; ++u) {
                             const int at = wave + (round + u) * kWaves;
-                            uint32_t first = 0, end = 0, value = 0;
-                            if (at < n_items) locate(at, first, end, value);
-                            live[u] = first < end && DS_OK_INDEX(3, first, a.n_quads);
+                            uint32_t first = 0, value = 0;
+                            live[u] = at < n_items && locate(at, first, value) && DS_OK_INDEX(3, first, a.n_quads);
                             quad[u] = live[u] ? load_quad(quads, first) : make_uint2(kSentinel * 0x10001u, kSentinel * 0x10001u);
                             quad_info[u] = live[u] ? load_quad(sums_quads, first) : make_uint2(0xff00ff00u, 0xff00ff00u);
                         }
