@@ -7,7 +7,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-_SOURCES = ("ds_runtime.hip", "ds_jaccard.hip", "ds_features.hip", "ds_build.hip", "ds_forest.hip", "ds_pairs.hip")
+_SOURCES = ("ds_runtime.hip", "ds_jaccard.hip", "ds_jaccard_wide.hip", "ds_jaccard_narrow.hip", "ds_features.hip",
+            "ds_build.hip", "ds_forest.hip", "ds_pairs.hip")
 _lib = None
 
 
@@ -28,7 +29,7 @@ def source_id():
         if not os.path.isdir(directory):
             return None
         files += [os.path.join(directory, name) for name in sorted(os.listdir(directory))
-                  if name.endswith((".hip", ".h"))]
+                  if name.endswith((".hip", ".h", ".inc"))]
     digest = hashlib.sha256()
     for path in files:
         digest.update(os.path.basename(path).encode() + b"\0")
@@ -55,12 +56,27 @@ def build_library(force=False, verbose=False):
     wanted = source_id()
     if not force and binary_id(target) == wanted:
         return target
-    command = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               f'-DDS_BUILD_ID="{wanted}"', "-I", os.path.join(_ROOT, "include"), "-o", target] + \
-        os.environ.get("DS_BUILD_FLAGS", "").split() + sources
-    if verbose:
-        print(" ".join(command))
-    subprocess.check_call(command)
+    # one hipcc per translation unit, side by side (the two geometries of the Jaccard kernels take a minute each), then
+    # one link step
+    import concurrent.futures
+    import tempfile
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f'-DDS_BUILD_ID="{wanted}"', "-I",
+             os.path.join(_ROOT, "include")] + os.environ.get("DS_BUILD_FLAGS", "").split()
+    with tempfile.TemporaryDirectory(prefix="ds_build_") as scratch:
+        objects = [os.path.join(scratch, os.path.basename(source) + ".o") for source in sources]
+
+        def compile_one(pair):
+            source, output = pair
+            command = ["hipcc"] + flags + ["-c", source, "-o", output]
+            if verbose:
+                print(" ".join(command), flush=True)
+            subprocess.check_call(command)
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(4, len(sources))) as pool:
+            list(pool.map(compile_one, zip(sources, objects)))
+        link = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objects
+        if verbose:
+            print(" ".join(link), flush=True)
+        subprocess.check_call(link)
     return target
 
 

@@ -14,28 +14,15 @@
 
 namespace ds {
 
-// ---- geometry of the Jaccard kernels (see DESIGN.md "HBM layout") ------------------------------------------------
-// Fast kernel: two 512-thread workgroups per CU (independent queries hide each other's latencies and barriers); a
-// workgroup's score tile holds one 16-bit fixed-point score per row, two rows per LDS word.
-#ifndef DS_TILE_ROWS
-#define DS_TILE_ROWS 28672
-#endif
-#ifndef DS_CANDIDATES
-#define DS_CANDIDATES 1600
-#endif
-#ifndef DS_PTR_TILES
-#define DS_PTR_TILES 3
-#endif
-constexpr int kTile = DS_TILE_ROWS;          // truth rows per tile (multiple of 4096): 56 KiB of packed 16-bit scores
-constexpr int kSentinel = kTile;             // padding entry of a posting quad: lands in the trash word after the tile
-constexpr int kThreads = 512;                // fast kernel: 8 waves per workgroup, 2 workgroups per CU
-constexpr int kWorkgroupsPerCu = 2;
+// ---- two geometries of the Jaccard kernels (chosen per index by ds_index_create) ---------------
+//   wide    2 workgroups of 512 threads per CU, tiles of 28672 truth rows  (large truth sets: fewer tiles per query)
+//   narrow  4 workgroups of 256 threads per CU, tiles of 12288 truth rows  (up to kNarrowMaxTruth rows: four independent
+//           queries per CU hide each other's barriers and load latencies, and the dense first tile is smaller)
+// ds_jaccard_impl.inc is compiled once per geometry (ds_jaccard_wide.hip / ds_jaccard_narrow.hip).
+constexpr int kWideTileRows = 28672, kNarrowTileRows = 12288;
+constexpr int64_t kNarrowMaxTruth = 2000000;
 constexpr int kDenseThreads = 1024;          // literal kernel: one 16-wave workgroup per CU, float32 score tile
-static_assert(kTile % 4096 == 0 && kTile < 65536, "tile rows: whole scan iterations, 16-bit local indexes");
 constexpr int kMaxQueryColumns = 128;        // fast-path limit (example data: p99 50, max 96 tri-grams per title)
-constexpr int kCandidates = DS_CANDIDATES;            // capacity of the per-query candidate buffer in LDS
-constexpr int kSelectSlack = 256;            // a selection that keeps more than kCandidates - kSelectSlack hands the query over
-constexpr int kPtrTiles = DS_PTR_TILES;                 // tiles whose list pointers are cached in LDS at a time
 constexpr int kSignatureBits = 128;          // densest columns whose membership is kept as a per-row bit (uint4)
 constexpr int kSignatureWords = kSignatureBits / 32;
 constexpr int kControlWords = 32;            // int32 control block in HBM (queue heads, counters)
@@ -122,6 +109,7 @@ struct DeviceBuffer {
 struct ds_index {
     int device = 0;
     int64_t n_truth = 0, n_columns = 0, nnz = 0, n_tiles = 0, n_quads = 0;
+    int tile_rows = 0;                     // kWideTileRows or kNarrowTileRows: selects the kernels' geometry
     float sums_min = 0.f;
     ds::DeviceBuffer<uint32_t> col_ptr;    // [n_columns][n_tiles + 1], unit = quads of 4 postings (column-major)
     ds::DeviceBuffer<uint16_t> postings;   // [n_quads * 4] tile-local truth rows, kSentinel-padded per (column, tile)

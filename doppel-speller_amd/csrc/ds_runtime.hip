@@ -1,5 +1,6 @@
 // Library plumbing: error reporting, device memory, timers, and the construction of the tiled truth index in HBM.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "ds_common.h"
@@ -135,8 +136,8 @@ int ds_device_name(int device, char *name, size_t capacity)
 
 // ---- tiled index ---------------------------------------------------------------------------------------------------
 // Input: the V x N inverted index of match_maker.py:122-133 in CSR form.  Output (HBM): the truth rows are cut
-// into tiles of kTile rows; every column's posting list is stored tile after tile as uint16 tile-local rows, each
-// (column, tile) sub-list padded to a multiple of four entries ("quad", one 8-byte load per lane) with kSentinel;
+// into tiles of tile_rows rows (28672 or 12288: the geometry); every column's posting list is stored tile after tile as uint16 tile-local rows, each
+// (column, tile) sub-list padded to a multiple of four entries ("quad", one 8-byte load per lane) with the sentinel tile_rows;
 // col_ptr[column][tile] is the first quad of that sub-list, col_ptr[column][n_tiles] the end of the column.
 // The constant per-posting value of match_maker.py:130 is never stored.
 int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float *idf32, const float *sums32,
@@ -147,11 +148,17 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     DS_REQUIRE(rowptr && idf32 && sums32, "ds_index_create: null input");
     DS_REQUIRE(V > 0 && N > 0, "ds_index_create: V and N must be positive (V=%lld N=%lld)", (long long)V,
                (long long)N);
-    DS_REQUIRE(N < (int64_t(1) << 31) - ds::kTile, "ds_index_create: N too large for int32 row indexes");
+    DS_REQUIRE(N < (int64_t(1) << 31) - ds::kWideTileRows, "ds_index_create: N too large for int32 row indexes");
+    // geometry: narrow tiles for truth sets of up to kNarrowMaxTruth rows (DS_GEOMETRY=wide|narrow overrides, for tests)
+    int64_t tile_rows = N <= ds::kNarrowMaxTruth ? ds::kNarrowTileRows : ds::kWideTileRows;
+    if (const char *geometry = getenv("DS_GEOMETRY"); geometry != nullptr) {
+        if (std::strcmp(geometry, "wide") == 0) tile_rows = ds::kWideTileRows;
+        if (std::strcmp(geometry, "narrow") == 0) tile_rows = ds::kNarrowTileRows;
+    }
     DS_REQUIRE(rowptr[0] == 0, "ds_index_create: rowptr[0] must be 0");
     const int64_t nnz = rowptr[V];
     DS_REQUIRE(nnz >= 0 && (nnz == 0 || truth_idx), "ds_index_create: bad nnz / truth_idx");
-    const int64_t n_tiles = (N + ds::kTile - 1) / ds::kTile;
+    const int64_t n_tiles = (N + tile_rows - 1) / tile_rows;
     const int64_t stride = n_tiles + 1;
     DS_REQUIRE(V * stride < (int64_t(1) << 40), "ds_index_create: list pointer table too large");
 
@@ -168,7 +175,7 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
                        "ds_index_create: posting list of column %lld is not strictly ascending within [0, N)",
                        (long long)g);
             previous = t;
-            ++row[t / ds::kTile];
+            ++row[t / tile_rows];
         }
         for (int64_t b = 0; b < n_tiles; ++b) {
             const uint32_t count = row[b];
@@ -181,7 +188,7 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     float sums_min = sums32[0];
     std::vector<float> tile_sums_min(static_cast<size_t>(n_tiles), 0.f);
     for (int64_t b = 0; b < n_tiles; ++b) {
-        const int64_t first = b * ds::kTile, last = std::min<int64_t>(N, first + ds::kTile);
+        const int64_t first = b * tile_rows, last = std::min<int64_t>(N, first + tile_rows);
         float lowest = sums32[first];
         for (int64_t t = first + 1; t < last; ++t) lowest = std::min(lowest, sums32[t]);
         tile_sums_min[static_cast<size_t>(b)] = lowest;
@@ -209,7 +216,7 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     }
 
     // pass 2: fill
-    std::vector<uint16_t> postings(static_cast<size_t>(quads) * 4, static_cast<uint16_t>(ds::kSentinel));
+    std::vector<uint16_t> postings(static_cast<size_t>(quads) * 4, static_cast<uint16_t>(tile_rows));  // the sentinel = tile_rows: the trash word
     std::vector<uint16_t> posting_sums(static_cast<size_t>(quads) * 4, static_cast<uint16_t>(0xff00));
     for (int64_t g = 0; g < V; ++g) {
         const uint32_t *row = col_ptr.data() + g * stride;
@@ -217,14 +224,14 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
         uint64_t write = 0;
         for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
             const int64_t t = truth_idx[p];
-            const int64_t b = t / ds::kTile;
+            const int64_t b = t / tile_rows;
             if (b != current_tile) {
                 current_tile = b;
                 write = static_cast<uint64_t>(row[b]) * 4u;
             }
             posting_sums[write] = static_cast<uint16_t>((ds::encode_sums8(sums32[t]) << 8) |
                                                          (signature[static_cast<size_t>(t) * ds::kSignatureWords] & 0xffu));
-            postings[write++] = static_cast<uint16_t>(t % ds::kTile);
+            postings[write++] = static_cast<uint16_t>(t % tile_rows);
         }
     }
     // The pruning bounds of the fast kernel assume what match_maker.py:135-142,174 produce: 0 <= idf < inf and
@@ -252,6 +259,7 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     index->n_columns = V;
     index->nnz = nnz;
     index->n_tiles = n_tiles;
+    index->tile_rows = static_cast<int>(tile_rows);
     index->n_quads = static_cast<int64_t>(quads);
     index->sums_min = sums_min;
     index->literal_only = literal_only;
@@ -317,7 +325,7 @@ int ds_index_info(const ds_index *index, int64_t info[8])
     info[0] = index->n_truth;
     info[1] = index->n_columns;
     info[2] = index->nnz;
-    info[3] = ds::kTile;
+    info[3] = index->tile_rows;
     info[4] = index->n_tiles;
     info[5] = static_cast<int64_t>(index->col_ptr.bytes() + index->postings.bytes() + index->posting_sums.bytes() + index->idf32.bytes() +
                                    index->sums32.bytes() + index->signature.bytes() + index->sig_column.bytes() + index->dup_rank.bytes());

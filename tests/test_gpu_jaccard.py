@@ -185,6 +185,30 @@ def test_near_ties_that_are_not_twins_still_exact(oracle):
         _check(oracle, problem, k)
 
 
+@pytest.mark.parametrize("geometry,tile_rows", [("wide", 28672), ("narrow", 12288)])
+def test_both_geometries_on_reference_vectors(oracle, golden_match_maker_full, monkeypatch, geometry, tile_rows):
+    """The kernels are compiled for two geometries (2 x 512 threads / 28672-row tiles, 4 x 256 / 12288); an index picks
+    one by its size.  Forced here, each must reproduce the reference's answers on its whole example truth set and the
+    oracle's on a random index with ties."""
+    import doppel_speller_amd as ds
+    monkeypatch.setenv("DS_GEOMETRY", geometry)
+    g = golden_match_maker_full
+    index = ds.TruthIndex(g["rowptr"], g["truth_idx"], g["idf32"], g["sums32"])
+    assert index.info()["tile_rows"] == tile_rows
+    for k in (10, 100):
+        got = index.top_k(g["q_rowptr"], g["q_cols"], g["q_maxint"], k)
+        ok = g[f"margin_ok_k{k}"]
+        assert np.array_equal(got[ok], g[f"rows_k{k}"][ok])
+    for k in (1, 10, 100, 512):
+        stats = _check(oracle, _tie_problem(np.random.RandomState(5), 50000, 6000), k).sync()
+        assert stats["error_queries"] == 0
+        # the narrow geometry's candidate buffer (832 entries) is sized for the reference's top_n of 10 and 100
+        # (settings.py:55-56); at k = 512 it may hand a tie-heavy query to the literal kernel -- same answer
+        assert stats["dense_reasons"]["ties"] == 0 or (geometry == "narrow" and k == 512)
+    problem = _random_problem(np.random.RandomState(99), 98304, 3000, 96)
+    _check(oracle, problem, 25)
+
+
 def test_edge_cases(oracle):
     rng = np.random.RandomState(11)
     problem = _random_problem(rng, 5000, 800, 8)
@@ -251,7 +275,7 @@ def test_whole_example_truth_set(oracle, golden_match_maker_full):
     from conftest import golden_frames
     g = golden_match_maker_full
     index = ds.TruthIndex(g["rowptr"], g["truth_idx"], g["idf32"], g["sums32"])
-    assert index.info()["tiles"] == 2
+    assert index.info()["tiles"] >= 2
     for k in (10, 100):
         got = index.top_k(g["q_rowptr"], g["q_cols"], g["q_maxint"], k)
         ok = g[f"margin_ok_k{k}"]
