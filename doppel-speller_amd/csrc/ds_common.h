@@ -19,8 +19,17 @@ namespace ds {
 //   narrow  4 workgroups of 256 threads per CU, tiles of 12288 truth rows  (up to kNarrowMaxTruth rows: four independent
 //           queries per CU hide each other's barriers and load latencies, and the dense first tile is smaller)
 // ds_jaccard_impl.inc is compiled once per geometry (ds_jaccard_wide.hip / ds_jaccard_narrow.hip).
-constexpr int kWideTileRows = 28672, kNarrowTileRows = 12288;
-constexpr int64_t kNarrowMaxTruth = 2000000;
+#ifndef DS_WIDE_TILE_ROWS
+#define DS_WIDE_TILE_ROWS 28672
+#endif
+#ifndef DS_NARROW_TILE_ROWS
+#define DS_NARROW_TILE_ROWS 12288
+#endif
+#ifndef DS_NARROW_MAX_TRUTH
+#define DS_NARROW_MAX_TRUTH 2000000
+#endif
+constexpr int kWideTileRows = DS_WIDE_TILE_ROWS, kNarrowTileRows = DS_NARROW_TILE_ROWS;
+constexpr int64_t kNarrowMaxTruth = DS_NARROW_MAX_TRUTH;
 constexpr int kDenseThreads = 1024;          // literal kernel: one 16-wave workgroup per CU, float32 score tile
 constexpr int kMaxQueryColumns = 128;        // fast-path limit (example data: p99 50, max 96 tri-grams per title)
 constexpr int kSignatureBits = 128;          // densest columns whose membership is kept as a per-row bit (uint4)

@@ -1,13 +1,22 @@
 // The Jaccard kernels in their WIDE geometry: 2 workgroups of 512 threads per CU, tiles of 28672 truth rows (56 KiB of
 // packed scores per workgroup) -- truth sets above ds::kNarrowMaxTruth rows, where the number of tiles per query counts.
+#include "doppel_amd.h"
 #define DS_GEOMETRY_NAME wide
-#define DS_TILE_ROWS 28672
-#define DS_THREADS 512
-#define DS_WGS_PER_CU 2
-#ifndef DS_CANDIDATES
-#define DS_CANDIDATES 1600
+#ifndef DS_WIDE_THREADS
+#define DS_WIDE_THREADS 512
 #endif
-#ifndef DS_PTR_TILES
-#define DS_PTR_TILES 3
+#ifndef DS_WIDE_WGS_PER_CU
+#define DS_WIDE_WGS_PER_CU 2
 #endif
+#ifndef DS_WIDE_CANDIDATES
+#define DS_WIDE_CANDIDATES 1600
+#endif
+#ifndef DS_WIDE_PTR_TILES
+#define DS_WIDE_PTR_TILES 3
+#endif
+#define DS_TILE_ROWS ds::kWideTileRows
+#define DS_THREADS DS_WIDE_THREADS
+#define DS_WGS_PER_CU DS_WIDE_WGS_PER_CU
+#define DS_CANDIDATES DS_WIDE_CANDIDATES
+#define DS_PTR_TILES DS_WIDE_PTR_TILES
 #include "ds_jaccard_impl.inc"
