@@ -319,8 +319,8 @@ def main():
                     "bytes_per_query": requested / max(1, per_gpu),
                     "note": "algorithmic bytes = what THIS kernel requests from global memory per launch (2-byte "
                             "postings of the traversed lists + per-posting row info, sums32 of the dense scans, list "
-                            "pointers, per-column setup), counted by a second instantiation of the kernel in one extra "
-                            "untimed launch; `traffic` = 2 * FETCH_SIZE + WRITE_SIZE of profiles/pmc_latest.json "
+                            "pointers, per-column setup, refinement gathers, exact-stage probes), counted by a second "
+                            "instantiation of the kernel in one extra untimed launch; `traffic` = 2 * FETCH_SIZE + WRITE_SIZE of profiles/pmc_latest.json "
                             "(FETCH_SIZE counts half of coalesced streams on gfx950) when measured on this build"}
         pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_file):
