@@ -45,7 +45,7 @@ def main():
         print(f"{kernel}: {len(durations[kernel])} dispatches under PMC, mean {mean_ms:.3f} ms")
         for counter, value in sorted(counters.items()):
             print(f"    {counter:24s} {value:.6g} per dispatch")
-    kernel = next((name for name in per if "ds_jaccard_topk_kernel<false>" in name), None)
+    kernel = next((name for name in per if "ds_jaccard_topk_kernel<false" in name), None)
     if kernel is None:
         return
     c = per[kernel]
