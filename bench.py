@@ -129,6 +129,20 @@ def cpu_baseline(workload, k, budget_seconds):
             "queries_per_s": n_sample / tj, "feature_pairs_per_s": n_sample * k / tf}
 
 
+def resolve_config(name, world, queries=None, truth=None, k=None):
+    """(queries per GPU, truth titles, k, "weak" | "strong", BASELINE.json's text, overridden?) of a configuration on
+    `world` GPUs.  "per_gpu" configurations keep the per-GPU batch fixed (weak scaling); "total" ones divide a fixed
+    number of queries over the GPUs (strong scaling: C4 = 8M in all, C5 = 1M in all)."""
+    total_or_batch, mode, config_truth, config_k, text = CONFIGS[name]
+    per_gpu = total_or_batch if mode == "per_gpu" else total_or_batch // world
+    scaling = "weak" if mode == "per_gpu" else "strong"
+    custom = queries is not None or truth is not None or k is not None
+    if queries is not None:
+        per_gpu, scaling = queries, "weak"
+    return (per_gpu, truth if truth is not None else config_truth, k if k is not None else config_k, scaling, text,
+            custom)
+
+
 def spawn_ranks(gpus):
     """`--gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE this process touches the GPU and
     exit with their worst status.  Rank 0 inherits stdout (the JSON line); the other ranks' stdout goes to stderr."""
@@ -170,14 +184,7 @@ def main():
         log(f"error: --gpus {args.gpus} but WORLD_SIZE={world}")
         sys.exit(2)
 
-    queries, mode, truth, k, text = CONFIGS[args.config]
-    per_gpu = queries if mode == "per_gpu" else queries // world
-    scaling = "weak" if mode == "per_gpu" else "strong"
-    custom = args.queries is not None or args.truth is not None or args.k is not None
-    if args.queries is not None:
-        per_gpu, scaling = args.queries, "weak"
-    truth = args.truth if args.truth is not None else truth
-    k = args.k if args.k is not None else k
+    per_gpu, truth, k, scaling, text, custom = resolve_config(args.config, world, args.queries, args.truth, args.k)
     # DS_BENCH_FORCE_DIST=1 exercises the rendezvous / RCCL plumbing with a single rank (1-GPU rehearsal)
     distributed = world > 1 or os.environ.get("DS_BENCH_FORCE_DIST") == "1"
 

@@ -194,3 +194,24 @@ def test_pair_list_restatement_against_a_pandas_transcription(oracle):
     expected = dict(zip(matches["test_index"], matches["match"]))
     assert {int(q): int(m) for q, m in zip(query, match) if m >= 0} == expected
     assert len(expected) > 10 and (match < 0).sum() > 10
+
+
+def test_bench_configurations_follow_baseline_json():
+    """bench.py --config C2..C5: BASELINE.json's shapes, per GPU, for the GPU counts the driver uses."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.resolve_config("C2", 1)[:4] == (100_000, 500_000, 10, "weak")
+    assert bench.resolve_config("C2", 8)[:4] == (100_000, 500_000, 10, "weak")       # fixed per-GPU batch
+    assert bench.resolve_config("C3", 1)[:4] == (1_000_000, 5_000_000, 50, "weak")
+    assert bench.resolve_config("C4", 8)[:4] == (1_000_000, 5_000_000, 50, "strong")  # 8M queries in all
+    assert bench.resolve_config("C4", 2)[:4] == (4_000_000, 5_000_000, 50, "strong")
+    assert bench.resolve_config("C5", 8)[:4] == (125_000, 50_000_000, 100, "strong")  # 1M queries in all
+    assert bench.resolve_config("C5", 1)[:4] == (1_000_000, 50_000_000, 100, "strong")
+    per_gpu, truth, k, scaling, _, custom = bench.resolve_config("C2", 4, queries=2000, truth=60000)
+    assert (per_gpu, truth, k, scaling, custom) == (2000, 60000, 10, "weak", True)
+    import json
+    with open(os.path.join(ROOT, "BASELINE.json")) as handle:
+        configs = json.load(handle)["configs"]
+    assert "100k synthetic queries" in configs[1] and "1M queries" in configs[2] and "8M queries" in configs[3]
