@@ -112,7 +112,7 @@ def cpu_baseline(workload, k, budget_seconds):
     sweep = {}
     candidates = sorted({1, cores} | {t for t in (8, 16, 32, 64, 128) if t < cores})
     for threads in candidates:
-        pilot = min(workload.n_queries, max(2 * threads, 8))
+        pilot = min(workload.n_queries, max(4 * threads, 128))  # enough queries per thread for a stable ranking
         tj, tf = run(pilot, threads)
         sweep[threads] = pilot * k / (tj + tf)
         if tj + tf > budget_seconds / 3:
