@@ -196,7 +196,24 @@ def main():
     rendezvous = communicator = gather = None
     if distributed:
         rendezvous = Rendezvous.from_environment()
-        communicator = HostCommunicator(rendezvous) if args.host_communicator else RcclCommunicator(rendezvous, device)
+        communicator_note = None
+        if args.host_communicator:
+            communicator = HostCommunicator(rendezvous)
+        else:
+            # The path itself has no collective (queries are sharded, the truth index is replicated): the gather only
+            # assembles the result table.  If RCCL cannot be initialised the ranks AGREE (one flag each through the
+            # rendezvous) to gather through the host instead, and the line says so (`rccl_ranks` 0 + `communicator_note`).
+            try:
+                communicator, failure = RcclCommunicator(rendezvous, device), b""
+            except Exception as error:  # noqa: BLE001 - reported on the line, never hidden
+                communicator, failure = None, f"rank {rank}: {error}".encode()[:400]
+            failures = [f.decode() for f in rendezvous.all_gather_bytes(failure) if f]
+            if failures:
+                if communicator is not None:
+                    communicator.close()
+                communicator = HostCommunicator(rendezvous)
+                communicator_note = "RCCL initialisation failed, rows gathered through the host: " + "; ".join(failures)
+                log("warning: " + communicator_note)
 
     # ---- synthetic workload: truth replicated (same seed), queries distinct per rank
     t0 = time.perf_counter()
@@ -382,6 +399,8 @@ def main():
         }
         if distributed:
             line["rccl_ranks"] = world if communicator.on_device else 0
+            if communicator_note:
+                line["communicator_note"] = communicator_note
             line["collective"] = "ncclAllGather int32[queries_per_gpu, k] per step" if communicator.on_device else \
                 "host all-gather through the TCP rendezvous (rehearsal)"
         if next_rows:

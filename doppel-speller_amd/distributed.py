@@ -250,16 +250,25 @@ class RcclCommunicator:
     def __init__(self, rendezvous, device):
         self.rendezvous = rendezvous
         self.rank, self.world_size, self.device = rendezvous.rank, rendezvous.world_size, device
-        self.rccl = _load_rccl()
-        _lib.check(_lib.lib().ds_stream_sync(None, device), "select device")  # hipSetDevice(device) for RCCL
-        unique = _NcclUniqueId()
-        if self.rank == 0:
-            with _StdoutToStderr():
-                status = self.rccl.ncclGetUniqueId(ctypes.byref(unique))
-            self._check(status, "ncclGetUniqueId")
-        raw = rendezvous.broadcast_bytes(ctypes.string_at(ctypes.byref(unique), 128) if self.rank == 0 else None)
+        unique, failure = _NcclUniqueId(), None
+        try:
+            self.rccl = _load_rccl()
+            _lib.check(_lib.lib().ds_stream_sync(None, device), "select device")  # hipSetDevice(device) for RCCL
+            if self.rank == 0:
+                with _StdoutToStderr():
+                    status = self.rccl.ncclGetUniqueId(ctypes.byref(unique))
+                self._check(status, "ncclGetUniqueId")
+        except Exception as error:  # noqa: BLE001 - re-raised below, after the broadcast every rank takes part in
+            failure = error
+        # every rank reaches the broadcast whatever happened before it: rank 0 sends an empty id when it failed, so the
+        # other ranks raise instead of waiting for an id that never comes
+        raw = rendezvous.broadcast_bytes(
+            (b"" if failure else ctypes.string_at(ctypes.byref(unique), 128)) if self.rank == 0 else None)
+        if failure is not None:
+            raise failure
         if len(raw) != 128:
-            raise _lib.DoppelError("rendezvous delivered a malformed RCCL unique id")
+            raise _lib.DoppelError("rank 0 could not create an RCCL unique id" if not raw
+                                   else "rendezvous delivered a malformed RCCL unique id")
         ctypes.memmove(ctypes.byref(unique), raw, 128)
         self.comm = ctypes.c_void_p()
         with _StdoutToStderr():

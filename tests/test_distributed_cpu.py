@@ -120,3 +120,42 @@ def test_rendezvous_from_environment_when_the_preferred_port_is_taken(tmp_path):
     for rank in range(3):
         with open(f"{out}.{rank}", "rb") as handle:
             assert handle.read() == b"\x00\x00\x00\x01\x01\x01\x02\x02\x02"
+
+
+def _free_port():
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        return probe.getsockname()[1]
+
+
+def _rccl_failure_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    from doppel_speller_amd.distributed import RcclCommunicator, Rendezvous
+    rendezvous = Rendezvous(rank, world, port=port)
+    try:
+        RcclCommunicator(rendezvous, rank)
+        outcome = "initialised"
+    except Exception as error:  # noqa: BLE001 - the message is the result
+        outcome = f"{type(error).__name__}: {error}"
+    flags = rendezvous.all_gather_bytes(outcome.encode())   # the rendezvous is still in step on every rank
+    with open(f"{out_path}.{rank}", "w") as handle:
+        handle.write("\n".join(flag.decode() for flag in flags))
+    rendezvous.close()
+
+
+def test_rccl_initialisation_failure_raises_on_every_rank_without_hanging(tmp_path):
+    """No GPU here: rank 0 cannot select a device, so it never creates a unique id.  It still takes part in the id
+    broadcast (empty id): every rank raises and the rendezvous stays usable -- what bench.py's agreed fallback to the
+    host gather relies on."""
+    context = multiprocessing.get_context("spawn")
+    port = _free_port()
+    out = str(tmp_path / "outcome")
+    ranks = [context.Process(target=_rccl_failure_worker, args=(r, 2, port, out)) for r in range(2)]
+    for process in ranks:
+        process.start()
+    for process in ranks:
+        process.join(180)
+        assert process.exitcode == 0
+    for rank in range(2):
+        outcomes = open(f"{out}.{rank}").read().splitlines()
+        assert len(outcomes) == 2 and all("Error" in outcome for outcome in outcomes), outcomes

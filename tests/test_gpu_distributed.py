@@ -62,3 +62,28 @@ def test_bench_spawns_its_own_ranks():
     line = json.loads(result.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["queries_per_gpu"] == 2000 and line["verified_queries"] == 32
     assert line["value"] > 0 and line["roofline"]["frac"] <= 1.0
+
+
+def test_bench_under_the_driver_launcher_falls_back_loudly_when_rccl_refuses():
+    """The driver's own command line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 ...`) with both ranks on the box's only GPU: the launcher's store owns
+    MASTER_PORT, the rendezvous finds its own port, RCCL refuses the duplicate device on both ranks, and the ranks agree
+    to gather through the host -- one JSON line, `rccl_ranks` 0 and the reason on the line."""
+    import socket
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    env = dict(os.environ, DS_BENCH_SAME_DEVICE="1")
+    for name in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(name, None)
+    result = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                             "--gpus", "2", "--queries", "2000", "--truth", "60000", "--k", "10", "--steps", "1",
+                             "--warmup", "1", "--cpu-seconds", "0", "--check", "32"],
+                            env=env, capture_output=True, text=True, timeout=900)
+    assert result.returncode == 0, result.stderr[-3000:]
+    lines = [line for line in result.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, result.stdout[:2000]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["verified_queries"] == 32 and line["value"] > 0
+    assert line["rccl_ranks"] == 0 and "ncclCommInitRank" in line["communicator_note"]
