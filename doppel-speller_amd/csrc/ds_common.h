@@ -121,7 +121,7 @@ struct ds_index {
     int tile_rows = 0;                     // kWideTileRows or kNarrowTileRows: selects the kernels' geometry
     float sums_min = 0.f;
     ds::DeviceBuffer<uint32_t> col_ptr;    // [n_columns][n_tiles + 1], unit = quads of 4 postings (column-major)
-    ds::DeviceBuffer<uint16_t> postings;   // [n_quads * 4] tile-local truth rows, kSentinel-padded per (column, tile)
+    ds::DeviceBuffer<uint16_t> postings;   // [n_quads * 4] (parity << 15) | (tile-local row >> 1); per (column, tile): even rows, padding, odd rows, padding
     ds::DeviceBuffer<uint16_t> posting_sums; // [n_quads * 4] per posting: 8-bit lower bound of sums32[row] << 8 | signature bits 0..7
     ds::DeviceBuffer<float> idf32;         // [n_columns]
     ds::DeviceBuffer<float> sums32;        // [n_truth]

@@ -137,7 +137,7 @@ int ds_device_name(int device, char *name, size_t capacity)
 // ---- tiled index ---------------------------------------------------------------------------------------------------
 // Input: the V x N inverted index of match_maker.py:122-133 in CSR form.  Output (HBM): the truth rows are cut
 // into tiles of tile_rows rows (28672 or 12288: the geometry); every column's posting list is stored tile after tile as uint16 tile-local rows, each
-// (column, tile) sub-list padded to a multiple of four entries ("quad", one 8-byte load per lane) with the sentinel tile_rows;
+// (column, tile) sub-list holds its even rows, then its odd rows, each part padded to whole quads (one 8-byte load per lane; a posting = (parity << 15) | (local row >> 1), padding = the word after the tile);
 // col_ptr[column][tile] is the first quad of that sub-list, col_ptr[column][n_tiles] the end of the column.
 // The constant per-posting value of match_maker.py:130 is never stored.
 int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float *idf32, const float *sums32,
@@ -164,11 +164,13 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
 
     // pass 1: postings per (column, tile), validating the lists; then quads and offsets
     std::vector<uint32_t> col_ptr(static_cast<size_t>(V * stride), 0u);
+    std::vector<uint32_t> odd_count(static_cast<size_t>(n_tiles), 0u);
     uint64_t quads = 0;
     for (int64_t g = 0; g < V; ++g) {
         DS_REQUIRE(rowptr[g + 1] >= rowptr[g], "ds_index_create: rowptr not monotone at column %lld", (long long)g);
         uint32_t *row = col_ptr.data() + g * stride;
         int64_t previous = -1;
+        std::fill(odd_count.begin(), odd_count.end(), 0u);
         for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
             const int64_t t = truth_idx[p];
             DS_REQUIRE(t > previous && t < N,
@@ -176,12 +178,13 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
                        (long long)g);
             previous = t;
             ++row[t / tile_rows];
+            odd_count[static_cast<size_t>(t / tile_rows)] += static_cast<uint32_t>((t % tile_rows) & 1);
         }
         for (int64_t b = 0; b < n_tiles; ++b) {
-            const uint32_t count = row[b];
+            const uint32_t odd = odd_count[static_cast<size_t>(b)], even = row[b] - odd;
             DS_REQUIRE(quads < 0xfffffff0ull, "ds_index_create: more than 2^32 posting quads");
             row[b] = static_cast<uint32_t>(quads);
-            quads += (count + 3u) / 4u;
+            quads += (even + 3u) / 4u + (odd + 3u) / 4u;
         }
         row[n_tiles] = static_cast<uint32_t>(quads);
     }
@@ -215,23 +218,35 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
         }
     }
 
-    // pass 2: fill
-    std::vector<uint16_t> postings(static_cast<size_t>(quads) * 4, static_cast<uint16_t>(tile_rows));  // the sentinel = tile_rows: the trash word
+    // pass 2: fill.  A posting is (parity << 15) | (tile-local row >> 1): the LDS word of the row's packed score and the
+    // half of it.  Within a (column, tile) sub-list the even rows come first, then the odd rows, each part padded to whole
+    // quads with the word after the tile -- all four postings of a quad share their half, so the kernel derives shift and
+    // mask once per quad, and the sub-list is ascending in the encoded value (the exact stage searches it).
+    const uint16_t pad_word = static_cast<uint16_t>(tile_rows / 2);
+    std::vector<uint16_t> postings(static_cast<size_t>(quads) * 4, pad_word);
     std::vector<uint16_t> posting_sums(static_cast<size_t>(quads) * 4, static_cast<uint16_t>(0xff00));
     for (int64_t g = 0; g < V; ++g) {
         const uint32_t *row = col_ptr.data() + g * stride;
-        int64_t current_tile = -1;
-        uint64_t write = 0;
-        for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
-            const int64_t t = truth_idx[p];
-            const int64_t b = t / tile_rows;
-            if (b != current_tile) {
-                current_tile = b;
-                write = static_cast<uint64_t>(row[b]) * 4u;
+        int64_t p = rowptr[g];
+        while (p < rowptr[g + 1]) {
+            const int64_t b = truth_idx[p] / tile_rows;
+            int64_t last = p, even = 0;
+            while (last < rowptr[g + 1] && truth_idx[last] / tile_rows == b) {
+                even += ((truth_idx[last] % tile_rows) & 1) == 0;
+                ++last;
             }
-            posting_sums[write] = static_cast<uint16_t>((ds::encode_sums8(sums32[t]) << 8) |
-                                                         (signature[static_cast<size_t>(t) * ds::kSignatureWords] & 0xffu));
-            postings[write++] = static_cast<uint16_t>(t % tile_rows);
+            uint64_t write[2] = {static_cast<uint64_t>(row[b]) * 4u,
+                                 (static_cast<uint64_t>(row[b]) + static_cast<uint64_t>(even + 3) / 4u) * 4u};
+            for (uint64_t i = write[1]; i < static_cast<uint64_t>(row[b + 1]) * 4u; ++i)
+                postings[i] = static_cast<uint16_t>(0x8000u | pad_word);  // the odd part's padding
+            for (; p < last; ++p) {
+                const int64_t t = truth_idx[p];
+                const uint32_t local = static_cast<uint32_t>(t % tile_rows);
+                uint64_t &at = write[local & 1u];
+                posting_sums[at] = static_cast<uint16_t>((ds::encode_sums8(sums32[t]) << 8) |
+                                                          (signature[static_cast<size_t>(t) * ds::kSignatureWords] & 0xffu));
+                postings[at++] = static_cast<uint16_t>(((local & 1u) << 15) | (local >> 1));
+            }
         }
     }
     // The pruning bounds of the fast kernel assume what match_maker.py:135-142,174 produce: 0 <= idf < inf and
