@@ -37,15 +37,15 @@ constexpr int kSignatureWords = kSignatureBits / 32;
 constexpr int kControlWords = 32;            // int32 control block in HBM (queue heads, counters)
 
 // 8-bit lower bound of a positive float: 4 exponent bits (2^-3 .. 2^12) and 4 mantissa bits, truncated.
-// decode(encode(x)) <= x for every x >= 0; code 0 decodes to 0.
+// decode(encode(x)) <= x for every x >= 0; code 0 decodes to 0; a row never gets the padding code 0xff (values from 7936 up share 0xfe).
 inline uint32_t encode_sums8(float x)
 {
     if (!(x >= 0.125f)) return 0u;
     uint32_t bits;
     memcpy(&bits, &x, sizeof(bits));
     const int exponent = static_cast<int>(bits >> 23) - 124;  // 2^-3 -> 0
-    if (exponent > 15) return 0xffu;
-    return (static_cast<uint32_t>(exponent) << 4) | ((bits >> 19) & 0xfu);
+    if (exponent > 15) return 0xfeu;  // 0xff is the padding entries' code (never reachable in the collect sweep)
+    return std::min<uint32_t>(0xfeu, (static_cast<uint32_t>(exponent) << 4) | ((bits >> 19) & 0xfu));
 }
 
 // splitmix64 finaliser: a bijective 64-bit mixer (row-set hashes of the index build)

@@ -76,7 +76,9 @@ int ds_index_info(const ds_index *index, int64_t info[8]);
 /* For each query q: columns q_cols[q_rowptr[q] .. q_rowptr[q+1]) in ACCUMULATION ORDER (the order of
  * matrix_non_zero_columns[row], :118), q_maxint[q] = max_intersection_possible (:197, float64).
  * out_rows[q*k .. q*k+k) = truth ROW indexes in descending row-index order, exactly
- * `(array >= threshold).nonzero()[0][::-1][:k]` of :71 (the title_id mapping of :190 is the caller's). */
+ * `(array >= threshold).nonzero()[0][::-1][:k]` of :71 (the title_id mapping of :190 is the caller's).
+ * Inputs the reference cannot produce are still answered as its loop would answer them (by the literal kernel): a
+ * column listed twice in a query is added twice, more than 128 columns, a q_maxint below the columns' idf total. */
 int ds_jaccard_topk(ds_index *index, const int64_t *q_rowptr, const int32_t *q_cols, const double *q_maxint,
                     int64_t Q, int32_t k, int32_t *out_rows);
 /* Same with every array already in HBM; enqueues on `stream` and returns without synchronising.

@@ -392,3 +392,59 @@ def test_small_max_intersection_takes_the_literal_kernel(oracle):
     problem["q_maxint"][::2] *= 0.25
     index = _check(oracle, problem, 10)
     assert index.sync()["dense_queries"] >= 16
+
+
+@pytest.mark.parametrize("log2_scale", [11, 20, -12])
+def test_scaled_idf_values_stay_on_the_fast_kernel(oracle, log2_scale):
+    """IDF values scaled by a power of two (possible through the C ABI; every float32 sum scales exactly, so the
+    expected rows are those of the unscaled problem).  At 2^11 `sums32` reaches 10^4..10^5, beyond the range of the
+    8-bit sums code stored with every posting, whose top value is reserved for padding entries -- such rows share the
+    largest real code instead of becoming unreachable in the collect sweep; at 2^-12 every row has the smallest code."""
+    rng = np.random.RandomState(4242)
+    problem = _random_problem(rng, 40000, 900, 64)
+    unscaled = oracle.jaccard_topk(problem["rowptr"], problem["truth_idx"], problem["idf32"], problem["sums32"],
+                                   problem["q_rowptr"], problem["q_cols"], problem["q_maxint"], 10)
+    scale = 2.0 ** log2_scale
+    problem["idf32"] = problem["idf32"] * np.float32(scale)
+    problem["sums32"] = problem["sums32"] * np.float32(scale)
+    problem["q_maxint"] = problem["q_maxint"] * scale
+    assert log2_scale != 11 or problem["sums32"].max() > 7936.0
+    index = _check(oracle, problem, 10)
+    stats = index.sync()
+    assert stats["error_queries"] == 0 and stats["dense_queries"] <= 2
+    got = index.top_k(problem["q_rowptr"], problem["q_cols"], problem["q_maxint"], 10)
+    assert np.array_equal(got, unscaled)
+
+
+@pytest.mark.parametrize("k", [1, 10, 50])
+def test_a_column_listed_twice_in_a_query(oracle, k):
+    """Impossible from match_maker.py:196, possible through the C ABI: the reference's loop adds such a column twice
+    (so does the oracle).  The fast kernel's signature completion would count a skipped column once, so a pass after
+    it hands every query with a repeated column to the literal kernel; clean queries of the same call stay fast."""
+    import doppel_speller_amd as ds
+    rng = np.random.RandomState(5)
+    problem = _random_problem(rng, 60000, 700, 200, heavy=12)
+    q_rowptr, q_cols, q_maxint, repeated = [0], [], [], []
+    for q in range(200):
+        c = problem["q_cols"][problem["q_rowptr"][q]:problem["q_rowptr"][q + 1]]
+        if q % 4 == 3:   # every fourth query stays clean -- but lists its columns in random order (float32 sums follow it)
+            listed = c.copy()
+            rng.shuffle(listed)
+        else:
+            listed = np.concatenate((c, c[rng.rand(c.shape[0]) < 0.4], np.arange(12)[rng.rand(12) < 0.5],
+                                     np.arange(12)[rng.rand(12) < 0.5]))
+            rng.shuffle(listed)
+        repeated.append(np.unique(listed).shape[0] != listed.shape[0])
+        q_cols.append(listed.astype(np.int32))
+        q_rowptr.append(q_rowptr[-1] + listed.shape[0])
+        total = 0.0
+        for g in listed:
+            total = total + float(problem["idf32"][g])
+        q_maxint.append(total)
+    problem["q_rowptr"] = np.array(q_rowptr, np.int64)
+    problem["q_cols"] = np.concatenate(q_cols)
+    problem["q_maxint"] = np.array(q_maxint)
+    index = _check(oracle, problem, k)
+    status = index.status(200)
+    assert np.array_equal(status == 1, np.array(repeated)) or (status[~np.array(repeated)] <= 1).all()
+    assert (status[np.array(repeated)] == 1).all() and index.sync()["error_queries"] == 0
