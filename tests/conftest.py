@@ -54,6 +54,13 @@ def golden_features():
 
 
 @pytest.fixture(scope="session")
+def golden_features_edge():
+    """construct_features of the reference on 126 pairs the example data does not contain (spaces at both ends, runs of
+    spaces, > 15 words, one-character and 254-character titles ...), for three values of n_truth."""
+    return dict(np.load(os.path.join(GOLDEN, "construct_features_edge.npz"), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
 def golden_kat():
     import json
     with open(os.path.join(GOLDEN, "kat.json")) as handle:

@@ -23,7 +23,8 @@ numba 0.45" are listed in SURVEY.md section 8c and in oracle/README.md; every ca
 `*_margin_ok` flag saying whether it is insensitive to those differences.  Nothing is written under /root/reference
 (PYTHONDONTWRITEBYTECODE is forced, the example CSVs are unpacked into a temp dir).
 
-Usage:  PYTHONHASHSEED=0 python tests/golden/make_golden.py
+Usage:  PYTHONHASHSEED=0 python tests/golden/make_golden.py            (every fixture)
+        PYTHONHASHSEED=0 python tests/golden/make_golden.py --only edge (sections E and F only: construct_features_edge.npz, arg_top_k_cases.npz)
 """
 import os
 import sys
@@ -158,6 +159,123 @@ def _match_maker_answers(match_maker, s, mm, q_maxint, n_query, top_n):
     return rows, margin_ok
 
 
+def _edge_section(feature_engineering, encoding, alphabet):
+    """E. construct_features on pairs the example data does not contain: leading / trailing / repeated spaces, more
+    than 15 words, one-character titles, 255-character titles, words longer than the other title, identical and
+    disjoint titles, zero and huge word counts, n_truth = 1.  Inputs are built AT the kernel boundary (encoded arrays),
+    the answers come from the reference's own construct_features."""
+    rng = np.random.RandomState(777)
+    letters = [ch for ch in alphabet if ch not in (alphabet[0], " ")]
+
+    def word(n):
+        return "".join(rng.choice(letters) for _ in range(n))
+
+    def sentence(n_words, longest=9):
+        return " ".join(word(rng.randint(1, longest + 1)) for _ in range(n_words))
+
+    texts = [
+        ("a", "a"), ("a", "b"), ("a", "ab cd"), ("ab cd", "a"), (" a", "a "), ("a  b", "a b"), ("  ", "a"), ("a", "   "),
+        (" leading", "leading"), ("trailing ", "trailing"), ("two  spaces  here", "two spaces here"),
+        ("x" * 127, "x" * 128), ("x" * 128, "y" * 127), ("ab " * 42, "ab " * 42), ("a " * 63 + "a", "a " * 63 + "b"),
+        ("abc", "x" * 200), ("x" * 200, "abc"), ("abcdefghij" * 20, "abcdefghij"), ("abcdefghij", "abcdefghij" * 20),
+        ("x" * 64, "x" * 65), ("x" * 65, "xy" * 32), ("ab" * 60, "ba" * 60), ("a" * 254, "a"), ("a", "b" * 254),
+        (sentence(16), sentence(16)), (sentence(20, 4), sentence(20, 4)), (sentence(15), sentence(15)),
+        (sentence(14), sentence(14)), (sentence(1, 60), sentence(1, 60)), (sentence(30, 3), sentence(2)), (sentence(40, 2), sentence(40, 2)),
+        ("the same title ltd", "the same title ltd"), ("same words other order", "order other words same"),
+        ("0123456789", "9876543210"), ("a b c d e f g h i j k l m n o p q", "a b c d e f g h i j k l m n o p q"),
+        ("a b c d e f g h i j k l m n o p q", "q p o n m l k j i h g f e d c b a"),
+    ]
+    for _ in range(90):
+        base = sentence(rng.randint(1, 8))
+        other = list(base)
+        for _ in range(rng.randint(0, 6)):
+            at = rng.randint(len(other) + 1)
+            action = rng.randint(3)
+            if action == 0 and len(other) > 1:
+                del other[min(at, len(other) - 1)]
+            elif action == 1:
+                other.insert(at, rng.choice(letters + [" "]))
+            else:
+                other.insert(at, " ")
+        texts.append(("".join(other)[:255] or "a", base))
+    # len(q) + len(t) <= 255: beyond that numba wraps the uint8 total (H5) while NumPy 2 raises OverflowError, so the
+    # reference cannot be run here on such pairs (the oracle follows the numba semantics; tests/test_gpu_features.py)
+    texts = [(q, t) for q, t in texts if len(q) > 0 and len(t) > 0 and len(q) + len(t) <= 255]
+
+    def encode(text):
+        out = np.zeros(255, dtype=np.uint8)
+        out[:len(text)] = [encoding[ch] for ch in text]
+        return out
+
+    n = len(texts)
+    title_len = np.array([len(q) for q, _ in texts], dtype=np.uint8)
+    truth_len = np.array([len(t) for _, t in texts], dtype=np.uint8)
+    title_enc = np.vstack([encode(q) for q, _ in texts])
+    truth_enc = np.vstack([encode(t) for _, t in texts])
+    counts = rng.randint(1, 30000, (n, 15)).astype(np.uint32)
+    counts[rng.rand(n, 15) < 0.15] = 0
+    counts[rng.rand(n, 15) < 0.10] = 1
+    counts[rng.rand(n, 15) < 0.05] = 4000000000
+    blocks = []
+    for n_truth in (np.uint32(30000), np.uint32(1), np.uint32(4000000000)):
+        features = np.zeros((n, feature_engineering.FEATURES_COUNT), dtype=np.float32)
+        dummy = np.zeros((feature_engineering.FEATURES_COUNT,), dtype=np.uint8)
+        with np.errstate(all="ignore"):
+            feature_engineering.construct_features(title_len, truth_len, title_enc, truth_enc, counts,
+                                                   np.uint8(encoding[" "]), n_truth, dummy, features)
+        blocks.append(features)
+    np.savez_compressed(
+        f"{HERE}/construct_features_edge.npz", title_len=title_len, truth_len=truth_len, title_enc=title_enc,
+        truth_enc=truth_enc, counts=counts, space_code=np.uint8(encoding[" "]),
+        n_truth=np.array([30000, 1, 4000000000], dtype=np.uint32), features=np.stack(blocks),
+        titles=np.array([q for q, _ in texts]), truth_titles=np.array([t for _, t in texts]))
+    print("construct_features edge pairs:", n, "x 3 n_truth values; NaNs:", int(np.isnan(np.stack(blocks)).sum()))
+
+
+def _arg_top_k_section(match_maker):
+    """F. fast_arg_top_k of the reference on crafted float64 arrays: ties at the k-th value, fewer than k positive values,
+    all zeros, negatives, values within float32 resolution of the k-th, k = 1 / k = len / k > len, few distinct values."""
+    rng = np.random.RandomState(4711)
+    cases = []
+
+    def add(array, k):
+        cases.append((np.asarray(array, dtype=np.float64), int(k)))
+
+    add([0.5, 0.25, 0.75, 0.1, 0.9], 1); add([0.5, 0.25, 0.75, 0.1, 0.9], 3); add([0.5, 0.25, 0.75, 0.1, 0.9], 5)
+    add([0.5, 0.25, 0.75, 0.1, 0.9], 8)                      # k > len
+    add(np.zeros(50), 10); add(np.full(50, 0.3), 10)         # nothing positive / everything tied
+    add([0.0, 0.2, 0.0, 0.0, 0.4, 0.0], 4)                   # fewer than k positive values
+    add([-1.0, 0.2, -0.5, 0.0, 0.4, -2.0], 2); add([-1.0, -0.2, -0.5], 2)
+    ties = np.zeros(400); ties[rng.choice(400, 60, replace=False)] = 0.625; ties[rng.choice(400, 5, replace=False)] = 0.8
+    for k in (1, 5, 6, 10, 64, 100):
+        add(ties, k)
+    base = rng.rand(600)
+    for k in (1, 10, 50, 600):
+        add(base, k)
+    kth = np.sort(base)[::-1][9]
+    near = base.copy()
+    near[rng.choice(600, 40, replace=False)] = kth - rng.choice([1e-9, 4e-7, 9.9e-7, 1.0e-6, 1.1e-6, 2e-6], 40)
+    near[rng.choice(600, 10, replace=False)] = kth + rng.choice([1e-9, 1e-7, 1e-6], 10)
+    add(near, 10); add(near, 11); add(near.astype(np.float32).astype(np.float64), 10)
+    for levels in (2, 3, 7):
+        few = rng.randint(0, levels, 900) / float(levels)
+        for k in (1, 10, 100, 512):
+            add(few, k)
+    sparse = np.zeros(5000); sparse[rng.choice(5000, 300, replace=False)] = rng.rand(300) ** 3
+    for k in (10, 100, 299, 300, 301, 512):
+        add(sparse, k)
+    arrays, ks, answers = [], [], []
+    for array, k in cases:
+        out = np.asarray(match_maker.fast_arg_top_k(array, k), dtype=np.int64)
+        arrays.append(array); ks.append(k); answers.append(out)
+    np.savez_compressed(
+        f"{HERE}/arg_top_k_cases.npz", k=np.array(ks, dtype=np.int32),
+        array_offsets=np.cumsum([0] + [a.shape[0] for a in arrays]).astype(np.int64), arrays=np.concatenate(arrays),
+        answer_offsets=np.cumsum([0] + [a.shape[0] for a in answers]).astype(np.int64),
+        answers=np.concatenate(answers) if answers else np.zeros(0, np.int64))
+    print("fast_arg_top_k cases:", len(cases), "answers shorter than k:", sum(a.shape[0] < k for a, k in zip(answers, ks)))
+
+
 def main():
     data_dir = tempfile.mkdtemp(prefix="ds_golden_")
     _stage_example_data(data_dir)
@@ -223,6 +341,12 @@ def main():
                      "ENCODING_FLOAT_BUFFER_f32_bits": int(np.float32(s.ENCODING_FLOAT_BUFFER).view(np.uint32)),
                      "FEATURES_COUNT": feature_engineering.FEATURES_COUNT},
     }
+    only_edge = "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "edge"
+    if only_edge:
+        _edge_section(feature_engineering, encoding, alphabet)
+        _arg_top_k_section(match_maker)
+        shutil.rmtree(data_dir)
+        return
     with open(f"{HERE}/kat.json", "w") as handle:
         json.dump(kat, handle, indent=1, sort_keys=True)
 
@@ -346,6 +470,8 @@ def main():
     np.savez_compressed(f"{HERE}/match_maker_30000x1000.npz", **full)
     print("30000 x 1000 margin_ok k10/k100:", int(full["margin_ok_k10"].sum()), int(full["margin_ok_k100"].sum()))
 
+    _edge_section(feature_engineering, encoding, alphabet)
+    _arg_top_k_section(match_maker)
     shutil.rmtree(data_dir)
     print("levenshtein KATs:", len(lev))
     print("match_maker margin_ok k10/k100:", int(fixture["margin_ok_k10"].sum()), int(fixture["margin_ok_k100"].sum()),

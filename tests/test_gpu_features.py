@@ -81,6 +81,26 @@ def test_construct_features_golden(oracle, golden_features):
     assert ulps.max() <= 1
 
 
+def test_construct_features_edge_pairs_golden(oracle, golden_features_edge):
+    """The reference's own answers on pairs the example data does not contain (section E of make_golden.py)."""
+    import doppel_speller_amd as ds
+    g = golden_features_edge
+    for block, n_truth in enumerate(g["n_truth"]):
+        captured = g["features"][block]
+        features = np.zeros_like(captured)
+        with np.errstate(all="ignore"):
+            ds.construct_features(g["title_len"], g["truth_len"], g["title_enc"], g["truth_enc"], g["counts"],
+                                  g["space_code"], n_truth, None, features)
+            spec = oracle.construct_features(g["title_len"], g["truth_len"], g["title_enc"], g["truth_enc"], g["counts"],
+                                             g["space_code"], n_truth, "numba")
+        assert np.array_equal(features.view(np.uint32), spec.view(np.uint32))
+        assert np.array_equal(features[:, :51].view(np.uint32), captured[:, :51].view(np.uint32))
+        ranks, reference = features[:, 51:], captured[:, 51:]
+        assert np.array_equal(np.isnan(ranks), np.isnan(reference))
+        finite = ~np.isnan(reference)
+        assert np.abs(ranks.view(np.int32).astype(np.int64) - reference.view(np.int32))[finite].max() <= 1
+
+
 def _random_pairs(rng, n, long_titles=False):
     space = 1
     def title(max_len):

@@ -87,6 +87,41 @@ def test_construct_features_bit_exact(oracle, golden_features):
     assert np.all(np.abs(ranks_spec.view(np.int32).astype(np.int64) - ranks_np.view(np.int32))[~np.isnan(ranks_np)] <= 1)
 
 
+def test_fast_arg_top_k_on_crafted_arrays(oracle):
+    """The reference's own fast_arg_top_k (make_golden.py, section F) on arrays the example data does not produce: ties
+    at the k-th value, fewer than k positive values (the answer is then shorter than k or falls back to the largest
+    indexes), all zeros, negatives, values within float32 resolution of the k-th, k = 1 / len / > len."""
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "arg_top_k_cases.npz"), allow_pickle=False))
+    assert g["k"].shape[0] >= 40
+    for case, k in enumerate(g["k"]):
+        array = g["arrays"][g["array_offsets"][case]:g["array_offsets"][case + 1]]
+        expected = g["answers"][g["answer_offsets"][case]:g["answer_offsets"][case + 1]]
+        for typing in ("numpy", "numba"):
+            got = oracle.fast_arg_top_k(array, int(k), typing)
+            assert np.array_equal(got, expected), (case, int(k), typing, got[:8], expected[:8])
+
+
+def test_construct_features_edge_pairs_bit_exact(oracle, golden_features_edge):
+    """Pairs the example data does not contain, answers captured from the reference's own construct_features
+    (tests/golden/make_golden.py, section E): leading / trailing / repeated spaces, more than 15 words, one-character
+    and 254-character titles, zero / huge word counts, n_truth = 1 and 4e9."""
+    g = golden_features_edge
+    assert g["features"].shape[0] == 3 and g["features"].shape[1] >= 120
+    for block, n_truth in enumerate(g["n_truth"]):
+        expected = g["features"][block]
+        with np.errstate(all="ignore"):
+            got = oracle.construct_features(g["title_len"], g["truth_len"], g["title_enc"], g["truth_enc"], g["counts"],
+                                            g["space_code"], n_truth, "numpy")
+            spec = oracle.construct_features(g["title_len"], g["truth_len"], g["title_enc"], g["truth_enc"], g["counts"],
+                                             g["space_code"], n_truth, "numba")
+        assert np.array_equal(got.view(np.uint32), expected.view(np.uint32))  # NaN / inf patterns included
+        assert np.array_equal(spec[:, :51].view(np.uint32), expected[:, :51].view(np.uint32))
+        ranks_spec, ranks_np = spec[:, 51:], expected[:, 51:]
+        assert np.array_equal(np.isnan(ranks_spec), np.isnan(ranks_np))
+        finite = ~np.isnan(ranks_np)
+        assert np.all(np.abs(ranks_spec.view(np.int32).astype(np.int64) - ranks_np.view(np.int32))[finite] <= 1)
+
+
 def test_construct_features_survey_example(oracle, golden_kat):
     # SURVEY.md section 8c: q='systematica imnvestments services limited', t='maxima technologies nl bv'
     q, t = "systematica imnvestments services limited", "maxima technologies nl bv"
