@@ -19,4 +19,7 @@
 #define DS_WGS_PER_CU DS_WIDE_WGS_PER_CU
 #define DS_CANDIDATES DS_WIDE_CANDIDATES
 #define DS_PTR_TILES DS_WIDE_PTR_TILES
+#ifndef DS_FAST_CONTROL_VOLATILE
+#define DS_FAST_CONTROL_VOLATILE 1  // measured: this geometry's fast kernel is 2.3 % slower with the relaxed-atomic control words
+#endif
 #include "ds_jaccard_impl.inc"
