@@ -34,6 +34,7 @@ constexpr int kDenseThreads = 1024;          // literal kernel: one 16-wave work
 constexpr int kMaxQueryColumns = 128;        // fast-path limit (example data: p99 50, max 96 tri-grams per title)
 constexpr int kSignatureBits = 128;          // densest columns whose membership is kept as a per-row bit (uint4)
 constexpr int kSignatureWords = kSignatureBits / 32;
+constexpr int kRowRecordWords = 8;          // 32-byte row record: signature, sums32, duplicate rank
 constexpr int kControlWords = 32;            // int32 control block in HBM (queue heads, counters)
 
 // 8-bit lower bound of a positive float: 4 exponent bits (2^-3 .. 2^12) and 4 mantissa bits, truncated.
@@ -126,9 +127,11 @@ struct ds_index {
     ds::DeviceBuffer<float> idf32;         // [n_columns]
     ds::DeviceBuffer<float> sums32;        // [n_truth]
     ds::DeviceBuffer<float> tile_sums_min; // [n_tiles] min(sums32) over the rows of each tile
-    ds::DeviceBuffer<uint32_t> signature;  // [n_truth][4] bit g = row is in the posting list of the g-th densest column
+    ds::DeviceBuffer<uint32_t> signature;  // [n_truth][8] one 32-byte record per row, ONE cache line per refined row: words 0..3 =
+                                           // signature (bit g = row is in the posting list of the g-th densest column), word 4 =
+                                           // sums32 bits, word 5 = duplicate rank (below), words 6..7 unused
     ds::DeviceBuffer<int8_t> sig_column;   // [n_columns] signature bit of a column, -1 for all but the 128 densest
-    ds::DeviceBuffer<uint16_t> dup_rank;   // [n_truth] rows with the same column set and sums32 bits but a larger index (saturating)
+    // duplicate rank of a row (word 5 of its record): rows with the same column set and sums32 bits but a larger index (saturating)
     bool literal_only = false;             // idf32 / sums32 hold negative or non-finite values: the bounds of the fast kernel
                                            // do not apply, every query takes the literal kernel
     ds::DeviceBuffer<int32_t> control;     // [16] work-queue head, slow-list length, error count, counters

@@ -290,9 +290,17 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
         status = index->sums32.upload(padded.data(), padded.size());
     }
     if (status == DS_OK) status = index->tile_sums_min.upload(tile_sums_min.data(), tile_sums_min.size());
-    if (status == DS_OK) status = index->signature.upload(signature.data(), signature.size());
+    if (status == DS_OK) {  // row records: what the refinement of a raw entry gathers, in one cache line
+        std::vector<uint32_t> records(static_cast<size_t>(N) * ds::kRowRecordWords, 0u);
+        for (int64_t t = 0; t < N; ++t) {
+            uint32_t *record = records.data() + static_cast<size_t>(t) * ds::kRowRecordWords;
+            for (int w = 0; w < ds::kSignatureWords; ++w) record[w] = signature[static_cast<size_t>(t) * ds::kSignatureWords + w];
+            std::memcpy(&record[4], &sums32[t], sizeof(float));
+            record[5] = dup_rank[static_cast<size_t>(t)];
+        }
+        status = index->signature.upload(records.data(), records.size());
+    }
     if (status == DS_OK) status = index->sig_column.upload(sig_column.data(), sig_column.size());
-    if (status == DS_OK) status = index->dup_rank.upload(dup_rank.data(), dup_rank.size());
     if (status == DS_OK) status = index->control.allocate(ds::kControlWords);
     if (status == DS_OK && (hipStreamCreate(&index->stream) != hipSuccess ||
                             hipEventCreate(&index->event_begin) != hipSuccess ||
@@ -343,7 +351,7 @@ int ds_index_info(const ds_index *index, int64_t info[8])
     info[3] = index->tile_rows;
     info[4] = index->n_tiles;
     info[5] = static_cast<int64_t>(index->col_ptr.bytes() + index->postings.bytes() + index->posting_sums.bytes() + index->idf32.bytes() +
-                                   index->sums32.bytes() + index->signature.bytes() + index->sig_column.bytes() + index->dup_rank.bytes());
+                                   index->sums32.bytes() + index->signature.bytes() + index->sig_column.bytes());
     info[6] = index->n_quads * 4;
     info[7] = 0;
     return DS_OK;
