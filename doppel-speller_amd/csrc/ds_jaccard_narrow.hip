@@ -22,7 +22,7 @@
 #define DS_CANDIDATES DS_NARROW_CANDIDATES
 #define DS_PTR_TILES DS_NARROW_PTR_TILES
 #ifndef DS_NARROW_EPOCH
-#define DS_NARROW_EPOCH 4  // measured: 20.78 (1) / 20.47 (2) / 19.87 ms (4) on C2; the 14-bit local rows leave two bits
+#define DS_NARROW_EPOCH 4  // measured on C2: 20.78 (1) / 20.47 (2) / 19.87 (4) / 19.70 (8, 800 candidates) / 19.98 ms (16); top-100: 28.96 (4) / 31.7 (8) / 34.3 ms (16)
 #endif
 #define DS_EPOCH_TILES DS_NARROW_EPOCH
 #include "ds_jaccard_impl.inc"

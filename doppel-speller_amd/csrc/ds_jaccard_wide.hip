@@ -9,7 +9,7 @@
 #define DS_WIDE_WGS_PER_CU 2
 #endif
 #ifndef DS_WIDE_CANDIDATES
-#define DS_WIDE_CANDIDATES 1600
+#define DS_WIDE_CANDIDATES 1536  // 512 bytes go to the raw entries' tile bytes (epochs of 4 tiles)
 #endif
 #ifndef DS_WIDE_PTR_TILES
 #define DS_WIDE_PTR_TILES 3
@@ -23,7 +23,7 @@
 #define DS_FAST_CONTROL_VOLATILE 1  // measured: this geometry's fast kernel is 2.3 % slower with the relaxed-atomic control words
 #endif
 #ifndef DS_WIDE_EPOCH
-#define DS_WIDE_EPOCH 2  // measured: 91.1 (1) / 88.9 ms (2) at the C3 shape; the 15-bit local rows leave one bit
+#define DS_WIDE_EPOCH 4  // measured at the C3 shape: 91.1 (1) / 88.9 (2) / 86.5 (4) / 85.9 ms (8); top-100: 58.4 (2) / 56.9 (4) / 56.8 (8)
 #endif
 #define DS_EPOCH_TILES DS_WIDE_EPOCH
 #include "ds_jaccard_impl.inc"
