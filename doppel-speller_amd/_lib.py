@@ -94,6 +94,7 @@ def _declare(handle):
         "ds_index_create": [p, p, p, p, c.c_int64, c.c_int64, c.c_int, c.POINTER(p)],
         "ds_index_info": [p, c.POINTER(c.c_int64)],
         "ds_index_duplicate_ranks": [p, p, p, c.c_int64, c.c_int64, p],
+        "ds_index_image_digest": [p, p, p, p, c.c_int64, c.c_int64, c.c_int64, p],
         "ds_index_option": [p, c.c_char_p, c.c_int64],
         "ds_jaccard_topk": [p, p, p, p, c.c_int64, c.c_int32, p],
         "ds_jaccard_topk_device": [p, p, p, p, c.c_int64, c.c_int32, p, p],
@@ -113,6 +114,8 @@ def _declare(handle):
         "ds_problem_info": [p, c.POINTER(c.c_int64)],
         "ds_problem_arrays": [p] + [c.POINTER(p)] * 9,
         "ds_transform_titles": [p, p, c.c_int64, c.c_int32, c.c_int32, p, p],
+        "ds_encode_titles": [p, p, c.c_int64, p, c.c_int64, p, p],
+        "ds_truth_word_counts": [p, p, c.c_int64, p, p],
         "ds_forest_create": [p, p, p, p, p, p, c.c_int32, c.c_int32, c.c_float, c.c_int, c.POINTER(p)],
         "ds_forest_predict": [p, p, c.c_int64, p, p],
         "ds_forest_predict_device": [p, p, c.c_int64, p, p, p],
@@ -145,12 +148,12 @@ def _declare(handle):
 
 EXPORTED_SYMBOLS = (
     "ds_last_error", "ds_version", "ds_build_id", "ds_device_count", "ds_device_name", "ds_index_create", "ds_index_destroy",
-    "ds_index_duplicate_ranks", "ds_index_option",
+    "ds_index_duplicate_ranks", "ds_index_image_digest", "ds_index_option",
     "ds_index_info", "ds_jaccard_topk", "ds_jaccard_topk_device", "ds_jaccard_sync", "ds_jaccard_status", "ds_construct_features",
     "ds_titles_create", "ds_titles_destroy", "ds_construct_features_indexed", "ds_construct_features_indexed_device",
     "ds_levenshtein_ratio_batch", "ds_close_matches", "ds_close_matches_device", "ds_remaining_pairs_counts_size", "ds_remaining_pairs_device",
     "ds_select_matches_device", "ds_problem_create",
-    "ds_problem_destroy", "ds_problem_info", "ds_problem_arrays", "ds_transform_titles", "ds_forest_create", "ds_forest_destroy",
+    "ds_problem_destroy", "ds_problem_info", "ds_problem_arrays", "ds_transform_titles", "ds_encode_titles", "ds_truth_word_counts", "ds_forest_create", "ds_forest_destroy",
     "ds_forest_predict", "ds_forest_predict_device", "ds_malloc", "ds_free", "ds_memcpy_h2d", "ds_memcpy_d2h", "ds_memset",
     "ds_stream_sync", "ds_memcpy_d2d_async", "ds_stream_create", "ds_stream_destroy", "ds_timer_create", "ds_timer_destroy", "ds_timer_start", "ds_timer_stop",
     "ds_timer_elapsed_ms")

@@ -1,9 +1,11 @@
 // Library plumbing: error reporting, device memory, timers, and the construction of the tiled truth index in HBM.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
 #include "ds_common.h"
+#include "ds_host.h"
 
 namespace ds {
 
@@ -25,6 +27,23 @@ int hip_failed(hipError_t error, const char *what, const char *file, int line)
     return DS_E_HIP;
 }
 
+// fn(thread, column, first posting, last posting) for every column's postings whose rows fall into the thread's row range:
+// the rows are cut into one contiguous range per thread and a thread finds its part of each (ascending) posting list by
+// binary search, so per-row accumulators are written by one thread only and see a row's columns in ascending order.
+template <typename F>
+static void for_postings_by_row_range(const int64_t *rowptr, const int32_t *truth_idx, int64_t V, int64_t N, int threads, F fn)
+{
+    parallel_ranges(N, threads, [&](int thread, int64_t row_begin, int64_t row_end) {
+        if (row_begin >= row_end) return;
+        for (int64_t g = 0; g < V; ++g) {
+            const int32_t *first = truth_idx + rowptr[g], *last = truth_idx + rowptr[g + 1];
+            const int32_t *from = std::lower_bound(first, last, static_cast<int32_t>(row_begin));
+            const int32_t *to = row_end > 0x7fffffffll ? last : std::lower_bound(from, last, static_cast<int32_t>(row_end));
+            if (from < to) fn(thread, g, from - truth_idx, to - truth_idx);
+        }
+    });
+}
+
 // Duplicate ranks ("ties"): truth rows with the same column set and the same sums32 bits have the
 // same jaccard for EVERY query; rank[t] = how many such rows have a larger row index than t (saturating at 65535).
 // fast_arg_top_k returns the k largest row indexes at or above its threshold (match_maker.py:71), so a row with
@@ -32,73 +51,99 @@ int hip_failed(hipError_t error, const char *what, const char *file, int line)
 // stay in).  Rows are grouped by a 128-bit hash of their column set from the last row down; a group member counts only
 // after its column list has been compared with the group's first row: a hash collision leaves the row's rank at 0,
 // which is always safe (a rank may under-count, never over-count).
+// Threaded: hashes and column lists are accumulated per row range; the grouping and the ranking run per hash bucket
+// (every thread owns the rows whose hash falls into its bucket and walks them from the last row down, so a group's
+// first row and the order of its members are what the sequential walk finds).
 void duplicate_ranks(const int64_t *rowptr, const int32_t *truth_idx, const float *sums32, int64_t V, int64_t N,
                      uint16_t *rank_out)
 {
+    const int threads = host_threads();
     std::vector<uint64_t> hash_a(static_cast<size_t>(N), 0u), hash_b(static_cast<size_t>(N), 0u);
     std::vector<uint32_t> row_columns(static_cast<size_t>(N), 0u);
+    std::vector<uint64_t> image_a(static_cast<size_t>(V)), image_b(static_cast<size_t>(V));
     for (int64_t g = 0; g < V; ++g) {
-        const uint64_t image_a = mix64(static_cast<uint64_t>(g) + 0x9e3779b97f4a7c15ull);
-        const uint64_t image_b = mix64(static_cast<uint64_t>(g) * 0xd6e8feb86659fd93ull + 0x2545f4914f6cdd1dull);
-        for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
+        image_a[static_cast<size_t>(g)] = mix64(static_cast<uint64_t>(g) + 0x9e3779b97f4a7c15ull);
+        image_b[static_cast<size_t>(g)] = mix64(static_cast<uint64_t>(g) * 0xd6e8feb86659fd93ull + 0x2545f4914f6cdd1dull);
+    }
+    for_postings_by_row_range(rowptr, truth_idx, V, N, threads, [&](int, int64_t g, int64_t from, int64_t to) {
+        const uint64_t a = image_a[static_cast<size_t>(g)], b = image_b[static_cast<size_t>(g)];
+        for (int64_t p = from; p < to; ++p) {
             const size_t t = static_cast<size_t>(truth_idx[p]);
-            hash_a[t] += image_a;
-            hash_b[t] += image_b;
+            hash_a[t] += a;
+            hash_b[t] += b;
             ++row_columns[t];
         }
-    }
-    struct Slot { uint64_t a, b; uint32_t bits; int32_t first; };
-    size_t capacity = 16;
-    while (capacity < static_cast<size_t>(N) * 2) capacity <<= 1;
-    std::vector<Slot> table(capacity, Slot{0u, 0u, 0u, -1});
-    std::vector<int32_t> group_first(static_cast<size_t>(N), -1);  // row -> first (largest) row of its hash group
-    int64_t grouped_columns = 0;
-    for (int64_t t = N - 1; t >= 0; --t) {
+    });
+    auto sums_bits = [&](int64_t t) {
         uint32_t bits;
         std::memcpy(&bits, &sums32[t], sizeof(bits));
-        const uint64_t a = hash_a[static_cast<size_t>(t)], b = hash_b[static_cast<size_t>(t)];
-        size_t at = static_cast<size_t>(mix64(a ^ (b << 1) ^ bits)) & (capacity - 1);
-        while (table[at].first >= 0 && !(table[at].a == a && table[at].b == b && table[at].bits == bits))
-            at = (at + 1) & (capacity - 1);
-        if (table[at].first < 0) {
-            table[at] = Slot{a, b, bits, static_cast<int32_t>(t)};
-        } else {
-            const size_t first = static_cast<size_t>(table[at].first);
-            if (group_first[first] < 0) {  // the group's first row joins with its first twin
-                group_first[first] = table[at].first;
-                grouped_columns += row_columns[first];
+        return bits;
+    };
+    const int buckets = std::min(threads, 128);  // a bucket id is stored in a byte
+    auto bucket_of = [&](int64_t t) {
+        return static_cast<int>(mix64(hash_a[static_cast<size_t>(t)] ^ (hash_b[static_cast<size_t>(t)] << 1) ^ sums_bits(t)) >> 40) % buckets;
+    };
+    std::vector<uint8_t> owner(static_cast<size_t>(N));
+    parallel_ranges(N, threads, [&](int, int64_t begin, int64_t end) {
+        for (int64_t t = begin; t < end; ++t) owner[static_cast<size_t>(t)] = static_cast<uint8_t>(bucket_of(t));
+    });
+    std::vector<int32_t> group_first(static_cast<size_t>(N), -1);  // row -> first (largest) row of its hash group
+    parallel_ranges(buckets, buckets, [&](int, int64_t bucket_begin, int64_t bucket_end) {
+        for (int64_t bucket = bucket_begin; bucket < bucket_end; ++bucket) {
+            size_t mine = 0;
+            for (int64_t t = 0; t < N; ++t) mine += owner[static_cast<size_t>(t)] == bucket;
+            struct Slot { uint64_t a, b; uint32_t bits; int32_t first; };
+            size_t capacity = 16;
+            while (capacity < mine * 2) capacity <<= 1;
+            std::vector<Slot> table(capacity, Slot{0u, 0u, 0u, -1});
+            for (int64_t t = N - 1; t >= 0; --t) {
+                if (owner[static_cast<size_t>(t)] != bucket) continue;
+                const uint32_t bits = sums_bits(t);
+                const uint64_t a = hash_a[static_cast<size_t>(t)], b = hash_b[static_cast<size_t>(t)];
+                size_t at = static_cast<size_t>(mix64(a ^ (b << 1) ^ bits)) & (capacity - 1);
+                while (table[at].first >= 0 && !(table[at].a == a && table[at].b == b && table[at].bits == bits))
+                    at = (at + 1) & (capacity - 1);
+                if (table[at].first < 0) {
+                    table[at] = Slot{a, b, bits, static_cast<int32_t>(t)};
+                } else {
+                    group_first[static_cast<size_t>(table[at].first)] = table[at].first;  // the first row joins with its first twin
+                    group_first[static_cast<size_t>(t)] = table[at].first;
+                }
             }
-            group_first[static_cast<size_t>(t)] = table[at].first;
-            grouped_columns += row_columns[static_cast<size_t>(t)];
         }
-    }
+    });
     // column lists of the grouped rows only (row-major; a row's columns arrive in ascending order)
     std::vector<int64_t> list_begin(static_cast<size_t>(N) + 1, 0);
     for (int64_t t = 0; t < N; ++t)
         list_begin[static_cast<size_t>(t) + 1] =
             list_begin[static_cast<size_t>(t)] + (group_first[static_cast<size_t>(t)] >= 0 ? row_columns[static_cast<size_t>(t)] : 0u);
-    std::vector<int32_t> lists(static_cast<size_t>(grouped_columns));
+    std::vector<int32_t> lists(static_cast<size_t>(list_begin[static_cast<size_t>(N)]));
     {
         std::vector<int64_t> fill(list_begin.begin(), list_begin.end() - 1);
-        for (int64_t g = 0; g < V; ++g)
-            for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
+        for_postings_by_row_range(rowptr, truth_idx, V, N, threads, [&](int, int64_t g, int64_t from, int64_t to) {
+            for (int64_t p = from; p < to; ++p) {
                 const size_t t = static_cast<size_t>(truth_idx[p]);
                 if (group_first[t] >= 0) lists[static_cast<size_t>(fill[t]++)] = static_cast<int32_t>(g);
             }
+        });
     }
     std::vector<uint32_t> twins(static_cast<size_t>(N), 0u);  // per group (at its first row): verified members so far
-    for (int64_t t = N - 1; t >= 0; --t) {
-        rank_out[t] = 0;
-        const int32_t first = group_first[static_cast<size_t>(t)];
-        if (first < 0 || first == t) continue;
-        const int64_t mine = list_begin[static_cast<size_t>(t)], theirs = list_begin[static_cast<size_t>(first)];
-        const uint32_t length = row_columns[static_cast<size_t>(t)];
-        if (length != row_columns[static_cast<size_t>(first)] ||
-            !std::equal(lists.begin() + mine, lists.begin() + mine + length, lists.begin() + theirs))
-            continue;  // a hash collision: the row keeps rank 0
-        const uint32_t rank = ++twins[static_cast<size_t>(first)];  // the group's first row + the twins before this one
-        rank_out[t] = static_cast<uint16_t>(std::min<uint32_t>(rank, 0xffffu));
-    }
+    parallel_ranges(buckets, buckets, [&](int, int64_t bucket_begin, int64_t bucket_end) {
+        for (int64_t bucket = bucket_begin; bucket < bucket_end; ++bucket)
+            for (int64_t t = N - 1; t >= 0; --t) {
+                if (owner[static_cast<size_t>(t)] != bucket) continue;
+                rank_out[t] = 0;
+                const int32_t first = group_first[static_cast<size_t>(t)];
+                if (first < 0 || first == t) continue;
+                const int64_t mine = list_begin[static_cast<size_t>(t)], theirs = list_begin[static_cast<size_t>(first)];
+                const uint32_t length = row_columns[static_cast<size_t>(t)];
+                if (length != row_columns[static_cast<size_t>(first)] ||
+                    !std::equal(lists.begin() + mine, lists.begin() + mine + length, lists.begin() + theirs))
+                    continue;  // a hash collision: the row keeps rank 0
+                const uint32_t rank = ++twins[static_cast<size_t>(first)];  // the group's first row + the twins before this one
+                rank_out[t] = static_cast<uint16_t>(std::min<uint32_t>(rank, 0xffffu));
+            }
+    });
 }
 
 }  // namespace ds
@@ -134,27 +179,47 @@ int ds_device_name(int device, char *name, size_t capacity)
     return DS_OK;
 }
 
+}  // extern "C"
+
 // ---- tiled index ---------------------------------------------------------------------------------------------------
 // Input: the V x N inverted index of match_maker.py:122-133 in CSR form.  Output (HBM): the truth rows are cut
 // into tiles of tile_rows rows (28672 or 12288: the geometry); every column's posting list is stored tile after tile as uint16 tile-local rows, each
 // (column, tile) sub-list holds its even rows, then its odd rows, each part padded to whole quads (one 8-byte load per lane; a posting = (parity << 15) | (local row >> 1), padding = the word after the tile);
 // col_ptr[column][tile] is the first quad of that sub-list, col_ptr[column][n_tiles] the end of the column.
 // The constant per-posting value of match_maker.py:130 is never stored.
-int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float *idf32, const float *sums32,
-                    int64_t V, int64_t N, int device, ds_index **out)
+namespace {
+
+// Everything ds_index_create derives on the host, ready for upload (also digested by ds_index_image_digest for tests).
+struct IndexImage {
+    int64_t n_tiles = 0, tile_rows = 0, nnz = 0;
+    uint64_t quads = 0;
+    float sums_min = 0.f;
+    bool literal_only = false;
+    std::vector<uint32_t> col_ptr, records;
+    std::vector<uint16_t> postings, posting_sums;
+    std::vector<float> tile_sums_min;
+    std::vector<int8_t> sig_column;
+};
+
+int64_t choose_tile_rows(int64_t N)
 {
-    DS_REQUIRE(out != nullptr, "ds_index_create: out is null");
-    *out = nullptr;
-    DS_REQUIRE(rowptr && idf32 && sums32, "ds_index_create: null input");
-    DS_REQUIRE(V > 0 && N > 0, "ds_index_create: V and N must be positive (V=%lld N=%lld)", (long long)V,
-               (long long)N);
-    DS_REQUIRE(N < (int64_t(1) << 31) - ds::kWideTileRows, "ds_index_create: N too large for int32 row indexes");
     // geometry: narrow tiles for truth sets of up to kNarrowMaxTruth rows (DS_GEOMETRY=wide|narrow overrides, for tests)
     int64_t tile_rows = N <= ds::kNarrowMaxTruth ? ds::kNarrowTileRows : ds::kWideTileRows;
     if (const char *geometry = getenv("DS_GEOMETRY"); geometry != nullptr) {
         if (std::strcmp(geometry, "wide") == 0) tile_rows = ds::kWideTileRows;
         if (std::strcmp(geometry, "narrow") == 0) tile_rows = ds::kNarrowTileRows;
     }
+    return tile_rows;
+}
+
+int build_index_image(const int64_t *rowptr, const int32_t *truth_idx, const float *idf32, const float *sums32,
+                      int64_t V, int64_t N, int64_t tile_rows, IndexImage &image)
+{
+    DS_REQUIRE(rowptr && idf32 && sums32, "ds_index_create: null input");
+    DS_REQUIRE(V > 0 && N > 0, "ds_index_create: V and N must be positive (V=%lld N=%lld)", (long long)V,
+               (long long)N);
+    DS_REQUIRE(N < (int64_t(1) << 31) - ds::kWideTileRows, "ds_index_create: N too large for int32 row indexes");
+    DS_REQUIRE(tile_rows > 0 && tile_rows % 2 == 0 && tile_rows / 2 < 0x8000, "ds_index_create: bad tile size");
     DS_REQUIRE(rowptr[0] == 0, "ds_index_create: rowptr[0] must be 0");
     const int64_t nnz = rowptr[V];
     DS_REQUIRE(nnz >= 0 && (nnz == 0 || truth_idx), "ds_index_create: bad nnz / truth_idx");
@@ -162,45 +227,71 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     const int64_t stride = n_tiles + 1;
     DS_REQUIRE(V * stride < (int64_t(1) << 40), "ds_index_create: list pointer table too large");
 
-    // pass 1: postings per (column, tile), validating the lists; then quads and offsets
+    const int threads = ds::host_threads();
+    const bool trace = getenv("DS_BUILD_LOG") != nullptr;  // phase times of the build on stderr
+    auto clock_now = [] { return std::chrono::steady_clock::now(); };
+    auto phase_started = clock_now();
+    auto phase = [&](const char *name) {
+        if (trace) fprintf(stderr, "ds_index_create: %-28s %7.3f s\n", name, std::chrono::duration<double>(clock_now() - phase_started).count());
+        phase_started = clock_now();
+    };
+    ds::FirstError error;
+
+    // pass 1 (threaded over columns): postings per (column, tile) -> quads, validating the lists; then the offsets
     std::vector<uint32_t> col_ptr(static_cast<size_t>(V * stride), 0u);
-    std::vector<uint32_t> odd_count(static_cast<size_t>(n_tiles), 0u);
+    for (int64_t g = 0; g < V; ++g)
+        DS_REQUIRE(rowptr[g + 1] >= rowptr[g], "ds_index_create: rowptr not monotone at column %lld", (long long)g);
+    ds::parallel_dynamic(V, 32, threads, [&](int, int64_t column_begin, int64_t column_end) {
+        for (int64_t g = column_begin; g < column_end; ++g) {
+            uint32_t *row = col_ptr.data() + g * stride;
+            int64_t previous = -1, p = rowptr[g];
+            const int64_t last = rowptr[g + 1];
+            while (p < last) {
+                if (!(truth_idx[p] > previous && truth_idx[p] < N)) {
+                    error.raise("ds_index_create: posting list of column %lld is not strictly ascending within [0, N)",
+                                (long long)g);
+                    return;
+                }
+                const int64_t b = truth_idx[p] / tile_rows, tile_end = (b + 1) * tile_rows;
+                uint32_t even = 0, odd = 0;
+                for (; p < last && truth_idx[p] > previous && truth_idx[p] < tile_end; ++p) {
+                    previous = truth_idx[p];
+                    const uint32_t parity = static_cast<uint32_t>(previous - b * tile_rows) & 1u;
+                    odd += parity;
+                    even += 1u - parity;
+                }
+                row[b] = (even + 3u) / 4u + (odd + 3u) / 4u;
+            }
+        }
+    });
+    DS_REQUIRE(!error.failed(), "%s", error.message());
     uint64_t quads = 0;
     for (int64_t g = 0; g < V; ++g) {
-        DS_REQUIRE(rowptr[g + 1] >= rowptr[g], "ds_index_create: rowptr not monotone at column %lld", (long long)g);
         uint32_t *row = col_ptr.data() + g * stride;
-        int64_t previous = -1;
-        std::fill(odd_count.begin(), odd_count.end(), 0u);
-        for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
-            const int64_t t = truth_idx[p];
-            DS_REQUIRE(t > previous && t < N,
-                       "ds_index_create: posting list of column %lld is not strictly ascending within [0, N)",
-                       (long long)g);
-            previous = t;
-            ++row[t / tile_rows];
-            odd_count[static_cast<size_t>(t / tile_rows)] += static_cast<uint32_t>((t % tile_rows) & 1);
-        }
         for (int64_t b = 0; b < n_tiles; ++b) {
-            const uint32_t odd = odd_count[static_cast<size_t>(b)], even = row[b] - odd;
+            const uint32_t here = row[b];
             DS_REQUIRE(quads < 0xfffffff0ull, "ds_index_create: more than 2^32 posting quads");
             row[b] = static_cast<uint32_t>(quads);
-            quads += (even + 3u) / 4u + (odd + 3u) / 4u;
+            quads += here;
         }
         row[n_tiles] = static_cast<uint32_t>(quads);
     }
-    float sums_min = sums32[0];
+    DS_REQUIRE(quads < 0xfffffff0ull, "ds_index_create: more than 2^32 posting quads");
+    phase("list pointers");
     std::vector<float> tile_sums_min(static_cast<size_t>(n_tiles), 0.f);
-    for (int64_t b = 0; b < n_tiles; ++b) {
-        const int64_t first = b * tile_rows, last = std::min<int64_t>(N, first + tile_rows);
-        float lowest = sums32[first];
-        for (int64_t t = first + 1; t < last; ++t) lowest = std::min(lowest, sums32[t]);
-        tile_sums_min[static_cast<size_t>(b)] = lowest;
-        sums_min = std::min(sums_min, lowest);
-    }
+    ds::parallel_dynamic(n_tiles, 16, threads, [&](int, int64_t tile_begin, int64_t tile_end) {
+        for (int64_t b = tile_begin; b < tile_end; ++b) {
+            const int64_t first = b * tile_rows, last = std::min<int64_t>(N, first + tile_rows);
+            float lowest = sums32[first];
+            for (int64_t t = first + 1; t < last; ++t) lowest = std::min(lowest, sums32[t]);
+            tile_sums_min[static_cast<size_t>(b)] = lowest;
+        }
+    });
+    float sums_min = sums32[0];
+    for (int64_t b = 0; b < n_tiles; ++b) sums_min = std::min(sums_min, tile_sums_min[static_cast<size_t>(b)]);
     // membership signature of the (up to) 128 densest columns: the columns a running threshold lets the kernel skip
     // first are the lowest-IDF = longest lists; one 4-byte load then replaces a binary search per skipped column
     std::vector<int8_t> sig_column(static_cast<size_t>(V), static_cast<int8_t>(-1));
-    std::vector<uint32_t> signature(static_cast<size_t>(N) * ds::kSignatureWords, 0u);
     {
         std::vector<int64_t> by_length(static_cast<size_t>(V));
         for (int64_t g = 0; g < V; ++g) by_length[static_cast<size_t>(g)] = g;
@@ -213,40 +304,6 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
             const int64_t g = by_length[bit];
             if ((rowptr[g + 1] - rowptr[g]) * 256 < N) break;  // not dense enough to be worth a bit
             sig_column[static_cast<size_t>(g)] = static_cast<int8_t>(bit);
-            for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p)
-                signature[static_cast<size_t>(truth_idx[p]) * ds::kSignatureWords + (bit >> 5)] |= 1u << (bit & 31);
-        }
-    }
-
-    // pass 2: fill.  A posting is (parity << 15) | (tile-local row >> 1): the LDS word of the row's packed score and the
-    // half of it.  Within a (column, tile) sub-list the even rows come first, then the odd rows, each part padded to whole
-    // quads with the word after the tile -- all four postings of a quad share their half, so the kernel derives shift and
-    // mask once per quad, and the sub-list is ascending in the encoded value (the exact stage searches it).
-    const uint16_t pad_word = static_cast<uint16_t>(tile_rows / 2);
-    std::vector<uint16_t> postings(static_cast<size_t>(quads) * 4, pad_word);
-    std::vector<uint16_t> posting_sums(static_cast<size_t>(quads) * 4, static_cast<uint16_t>(0xff00));
-    for (int64_t g = 0; g < V; ++g) {
-        const uint32_t *row = col_ptr.data() + g * stride;
-        int64_t p = rowptr[g];
-        while (p < rowptr[g + 1]) {
-            const int64_t b = truth_idx[p] / tile_rows;
-            int64_t last = p, even = 0;
-            while (last < rowptr[g + 1] && truth_idx[last] / tile_rows == b) {
-                even += ((truth_idx[last] % tile_rows) & 1) == 0;
-                ++last;
-            }
-            uint64_t write[2] = {static_cast<uint64_t>(row[b]) * 4u,
-                                 (static_cast<uint64_t>(row[b]) + static_cast<uint64_t>(even + 3) / 4u) * 4u};
-            for (uint64_t i = write[1]; i < static_cast<uint64_t>(row[b + 1]) * 4u; ++i)
-                postings[i] = static_cast<uint16_t>(0x8000u | pad_word);  // the odd part's padding
-            for (; p < last; ++p) {
-                const int64_t t = truth_idx[p];
-                const uint32_t local = static_cast<uint32_t>(t % tile_rows);
-                uint64_t &at = write[local & 1u];
-                posting_sums[at] = static_cast<uint16_t>((ds::encode_sums8(sums32[t]) << 8) |
-                                                          (signature[static_cast<size_t>(t) * ds::kSignatureWords] & 0xffu));
-                postings[at++] = static_cast<uint16_t>(((local & 1u) << 15) | (local >> 1));
-            }
         }
     }
     // The pruning bounds of the fast kernel assume what match_maker.py:135-142,174 produce: 0 <= idf < inf and
@@ -254,16 +311,112 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     // sums).  An index that violates this (possible through the C ABI) is served by the literal kernel only.
     bool literal_only = false;
     for (int64_t g = 0; g < V && !literal_only; ++g) literal_only = !(idf32[g] >= 0.f && idf32[g] < 1e30f);
-    for (int64_t t = 0; t < N && !literal_only; ++t) literal_only = !(sums32[t] >= 0.f && sums32[t] < 1e30f);
-    if (!literal_only) {
+    // one walk over the postings per row range (threaded): signature bits and the idf total of every row
+    std::vector<uint32_t> records(static_cast<size_t>(N) * ds::kRowRecordWords, 0u);  // row records, signature in words 0..3
+    {
         std::vector<double> row_total(static_cast<size_t>(N), 0.0);
-        for (int64_t g = 0; g < V; ++g)
-            for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) row_total[static_cast<size_t>(truth_idx[p])] += idf32[g];
-        for (int64_t t = 0; t < N && !literal_only; ++t)
-            literal_only = static_cast<double>(sums32[t]) < row_total[static_cast<size_t>(t)] * (1.0 - 1e-4);
+        ds::for_postings_by_row_range(rowptr, truth_idx, V, N, threads, [&](int, int64_t g, int64_t from, int64_t to) {
+            const double value = idf32[g];
+            for (int64_t p = from; p < to; ++p) row_total[static_cast<size_t>(truth_idx[p])] += value;
+            const int bit = sig_column[static_cast<size_t>(g)];
+            if (bit >= 0)
+                for (int64_t p = from; p < to; ++p)
+                    records[static_cast<size_t>(truth_idx[p]) * ds::kRowRecordWords + static_cast<size_t>(bit >> 5)] |= 1u << (bit & 31);
+        });
+        std::vector<uint8_t> violated(static_cast<size_t>(threads), 0);
+        ds::parallel_ranges(N, threads, [&](int thread, int64_t begin, int64_t end) {
+            bool bad = false;
+            for (int64_t t = begin; t < end && !bad; ++t)
+                bad = !(sums32[t] >= 0.f && sums32[t] < 1e30f) ||
+                      static_cast<double>(sums32[t]) < row_total[static_cast<size_t>(t)] * (1.0 - 1e-4);
+            violated[static_cast<size_t>(thread)] = bad;
+        });
+        for (uint8_t bad : violated) literal_only = literal_only || bad;
     }
+    phase("signatures + row totals");
+
+    // pass 2 (threaded over columns): fill.  A posting is (parity << 15) | (tile-local row >> 1): the LDS word of the row's packed score and the
+    // half of it.  Within a (column, tile) sub-list the even rows come first, then the odd rows, each part padded to whole
+    // quads with the word after the tile -- all four postings of a quad share their half, so the kernel derives shift and
+    // mask once per quad, and the sub-list is ascending in the encoded value (the exact stage searches it).
+    const uint16_t pad_word = static_cast<uint16_t>(tile_rows / 2);
+    std::vector<uint16_t> postings(static_cast<size_t>(quads) * 4), posting_sums(static_cast<size_t>(quads) * 4);
+    ds::parallel_dynamic(V, 32, threads, [&](int, int64_t column_begin, int64_t column_end) {
+        for (int64_t g = column_begin; g < column_end; ++g) {
+            const uint32_t *row = col_ptr.data() + g * stride;
+            int64_t p = rowptr[g];
+            while (p < rowptr[g + 1]) {
+                const int64_t b = truth_idx[p] / tile_rows, tile_first = b * tile_rows, tile_end = tile_first + tile_rows;
+                int64_t last = p, even = 0;
+                for (; last < rowptr[g + 1] && truth_idx[last] < tile_end; ++last) even += ((truth_idx[last] - tile_first) & 1) == 0;
+                uint64_t write[2] = {static_cast<uint64_t>(row[b]) * 4u,
+                                     (static_cast<uint64_t>(row[b]) + static_cast<uint64_t>(even + 3) / 4u) * 4u};
+                const uint64_t part_end[2] = {write[1], static_cast<uint64_t>(row[b + 1]) * 4u};
+                for (; p < last; ++p) {
+                    const int64_t t = truth_idx[p];
+                    const uint32_t local = static_cast<uint32_t>(t - tile_first);
+                    uint64_t &at = write[local & 1u];
+                    posting_sums[at] = static_cast<uint16_t>((ds::encode_sums8(sums32[t]) << 8) |
+                                                              (records[static_cast<size_t>(t) * ds::kRowRecordWords] & 0xffu));
+                    postings[at++] = static_cast<uint16_t>(((local & 1u) << 15) | (local >> 1));
+                }
+                for (int part = 0; part < 2; ++part)  // padding: the word behind the tile, code 255
+                    for (uint64_t i = write[part]; i < part_end[part]; ++i) {
+                        postings[i] = static_cast<uint16_t>((part << 15) | pad_word);
+                        posting_sums[i] = static_cast<uint16_t>(0xff00);
+                    }
+            }
+        }
+    });
+    phase("postings");
     std::vector<uint16_t> dup_rank(static_cast<size_t>(N), 0u);
     ds::duplicate_ranks(rowptr, truth_idx, sums32, V, N, dup_rank.data());
+    phase("duplicate ranks");
+    ds::parallel_ranges(N, threads, [&](int, int64_t begin, int64_t end) {  // row records: what the refinement of a raw
+        for (int64_t t = begin; t < end; ++t) {                             // entry gathers, in one cache line
+            uint32_t *record = records.data() + static_cast<size_t>(t) * ds::kRowRecordWords;
+            std::memcpy(&record[4], &sums32[t], sizeof(float));
+            record[5] = dup_rank[static_cast<size_t>(t)];
+        }
+    });
+    image.n_tiles = n_tiles;
+    image.tile_rows = tile_rows;
+    image.nnz = nnz;
+    image.quads = quads;
+    image.sums_min = sums_min;
+    image.literal_only = literal_only;
+    image.col_ptr.swap(col_ptr);
+    image.records.swap(records);
+    image.postings.swap(postings);
+    image.posting_sums.swap(posting_sums);
+    image.tile_sums_min.swap(tile_sums_min);
+    image.sig_column.swap(sig_column);
+    return DS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float *idf32, const float *sums32,
+                    int64_t V, int64_t N, int device, ds_index **out)
+{
+    DS_REQUIRE(out != nullptr, "ds_index_create: out is null");
+    *out = nullptr;
+    IndexImage image;
+    const auto started = std::chrono::steady_clock::now();
+    {
+        const int built = build_index_image(rowptr, truth_idx, idf32, sums32, V, N, N > 0 ? choose_tile_rows(N) : 0, image);
+        if (built != DS_OK) return built;
+    }
+    const int64_t n_tiles = image.n_tiles, tile_rows = image.tile_rows, nnz = image.nnz;
+    const uint64_t quads = image.quads;
+    const float sums_min = image.sums_min;
+    const bool literal_only = image.literal_only;
+    std::vector<uint32_t> &col_ptr = image.col_ptr, &records = image.records;
+    std::vector<uint16_t> &postings = image.postings, &posting_sums = image.posting_sums;
+    std::vector<float> &tile_sums_min = image.tile_sums_min;
+    std::vector<int8_t> &sig_column = image.sig_column;
     DS_HIP(hipSetDevice(device));
     hipDeviceProp_t properties;
     DS_HIP(hipGetDeviceProperties(&properties, device));
@@ -290,16 +443,7 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
         status = index->sums32.upload(padded.data(), padded.size());
     }
     if (status == DS_OK) status = index->tile_sums_min.upload(tile_sums_min.data(), tile_sums_min.size());
-    if (status == DS_OK) {  // row records: what the refinement of a raw entry gathers, in one cache line
-        std::vector<uint32_t> records(static_cast<size_t>(N) * ds::kRowRecordWords, 0u);
-        for (int64_t t = 0; t < N; ++t) {
-            uint32_t *record = records.data() + static_cast<size_t>(t) * ds::kRowRecordWords;
-            for (int w = 0; w < ds::kSignatureWords; ++w) record[w] = signature[static_cast<size_t>(t) * ds::kSignatureWords + w];
-            std::memcpy(&record[4], &sums32[t], sizeof(float));
-            record[5] = dup_rank[static_cast<size_t>(t)];
-        }
-        status = index->signature.upload(records.data(), records.size());
-    }
+    if (status == DS_OK) status = index->signature.upload(records.data(), records.size());
     if (status == DS_OK) status = index->sig_column.upload(sig_column.data(), sig_column.size());
     if (status == DS_OK) status = index->control.allocate(ds::kControlWords);
     if (status == DS_OK && (hipStreamCreate(&index->stream) != hipSuccess ||
@@ -313,7 +457,37 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
         delete index;
         return status;
     }
+    if (getenv("DS_BUILD_LOG") != nullptr)
+        fprintf(stderr, "ds_index_create: %-28s %7.3f s (host build + upload, %d threads)\n", "total",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count(), ds::host_threads());
     *out = index;
+    return DS_OK;
+}
+
+// Host-only: FNV-1a digests of the arrays ds_index_create would upload, for a given tile size (tests: the image must
+// not depend on the number of build threads).  digest[0..5] = col_ptr, postings, posting_sums, row records,
+// tile_sums_min, sig_column; digest[6] = posting quads; digest[7] = literal_only.
+int ds_index_image_digest(const int64_t *rowptr, const int32_t *truth_idx, const float *idf32, const float *sums32,
+                          int64_t V, int64_t N, int64_t tile_rows, uint64_t digest[8])
+{
+    DS_REQUIRE(digest != nullptr, "ds_index_image_digest: null digest");
+    IndexImage image;
+    const int built = build_index_image(rowptr, truth_idx, idf32, sums32, V, N, tile_rows, image);
+    if (built != DS_OK) return built;
+    auto fnv = [](const void *data, size_t bytes) {
+        const uint8_t *at = static_cast<const uint8_t *>(data);
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (size_t i = 0; i < bytes; ++i) h = (h ^ at[i]) * 0x100000001b3ull;
+        return h;
+    };
+    digest[0] = fnv(image.col_ptr.data(), image.col_ptr.size() * 4);
+    digest[1] = fnv(image.postings.data(), image.postings.size() * 2);
+    digest[2] = fnv(image.posting_sums.data(), image.posting_sums.size() * 2);
+    digest[3] = fnv(image.records.data(), image.records.size() * 4);
+    digest[4] = fnv(image.tile_sums_min.data(), image.tile_sums_min.size() * 4);
+    digest[5] = fnv(image.sig_column.data(), image.sig_column.size());
+    digest[6] = image.quads;
+    digest[7] = image.literal_only ? 1u : 0u;
     return DS_OK;
 }
 

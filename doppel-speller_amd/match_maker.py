@@ -142,18 +142,31 @@ class NativeProblem:
             np.cumsum([len(e) for e in encoded], out=offsets[1:])
             chars = np.frombuffer(b"".join(encoded), dtype=np.uint8) if offsets[-1] else np.zeros(1, dtype=np.uint8)
             return np.ascontiguousarray(chars), offsets
-        t_chars, t_offsets = pack(truth_titles)
-        q_chars, q_offsets = pack(query_titles)
+        self._create(*pack(truth_titles), *pack(query_titles), n_gram)
+
+    @classmethod
+    def from_flat(cls, truth_chars, truth_offsets, query_chars, query_offsets, n_gram=3):
+        """From concatenated byte strings + offsets[n + 1] (no per-title Python objects: the form that scales)."""
+        self = cls.__new__(cls)
+        self._create(truth_chars, truth_offsets, query_chars, query_offsets, n_gram)
+        return self
+
+    def _create(self, t_chars, t_offsets, q_chars, q_offsets, n_gram):
+        t_chars = np.ascontiguousarray(t_chars, dtype=np.uint8)
+        q_chars = np.ascontiguousarray(q_chars, dtype=np.uint8)
+        t_offsets = np.ascontiguousarray(t_offsets, dtype=np.int64)
+        q_offsets = np.ascontiguousarray(q_offsets, dtype=np.int64)
         self.handle = ctypes.c_void_p()
-        _lib.check(_lib.lib().ds_problem_create(_ptr(t_chars), _ptr(t_offsets), len(truth_titles), _ptr(q_chars),
-                                                _ptr(q_offsets), len(query_titles), n_gram,
+        _lib.check(_lib.lib().ds_problem_create(_ptr(t_chars), _ptr(t_offsets), t_offsets.shape[0] - 1, _ptr(q_chars),
+                                                _ptr(q_offsets), q_offsets.shape[0] - 1, n_gram,
                                                 ctypes.byref(self.handle)), "ds_problem_create")
         info = (ctypes.c_int64 * 8)()
         _lib.check(_lib.lib().ds_problem_info(self.handle, info), "ds_problem_info")
         self.n_truth, self.n_queries, self.n_columns, self.nnz, self.q_nnz, self.n_gram = list(info)[:6]
 
-    def arrays(self):
-        """Copies of the arrays (vocabulary keys, idf32, idf64, rowptr, truth_idx, sums32, q_rowptr, q_cols, q_maxint)."""
+    def arrays(self, copy=True):
+        """The arrays (vocabulary keys, idf32, idf64, rowptr, truth_idx, sums32, q_rowptr, q_cols, q_maxint).
+        copy=False returns read-only views of the handle's memory: keep this object alive as long as they are used."""
         pointers = [ctypes.c_void_p() for _ in range(9)]
         _lib.check(_lib.lib().ds_problem_arrays(self.handle, *[ctypes.byref(p) for p in pointers]), "ds_problem_arrays")
         spec = (("vocabulary_keys", np.uint32, self.n_columns), ("idf32", np.float32, self.n_columns),
@@ -167,7 +180,8 @@ class NativeProblem:
                 out[name] = np.zeros(0, dtype=dtype)
                 continue
             buffer = (ctypes.c_char * (count * np.dtype(dtype).itemsize)).from_address(pointer.value)
-            out[name] = np.frombuffer(buffer, dtype=dtype, count=count).copy()
+            view = np.frombuffer(buffer, dtype=dtype, count=count)
+            out[name] = view.copy() if copy else view
         return out
 
     def vocabulary(self):

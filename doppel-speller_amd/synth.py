@@ -10,9 +10,14 @@ requires.  Suffix shares follow the example data (ltd 27 %, limited 26 %, bv 16 
 Queries: 60 % are a truth title with 1-2 keyboard-style edits (the recipe of
 feature_engineering_prepare.py:90-173), 40 % are fresh titles.
 
-Measured at N = 500k (seed 20260101; SURVEY.md 8d targets in brackets): 21.2 tri-grams per title (21 +- 2), 50.3k
-tri-gram columns (~50k), postings touched per query 0.90 N (0.9 N +- 0.15 N), truth titles with a positive score per
-query 0.31 N (~0.33 N), 23.5 characters and 3.5 words per title (23.4, 3.5) -- asserted by
+Round 3: the titles are drawn by a small native generator (csrc/ds_synth.cpp -> libdoppel_synth.so, g++, threaded;
+one random stream per title, so the output does not depend on the thread count) and everything derived from them comes
+from the product's own host entry points -- `ds_problem_create` (vocabulary, IDF, inverted index, query rows: next
+row f-3), `ds_encode_titles` / `ds_truth_word_counts` (row a7).  The NumPy generator of rounds 1-2 took 316 s for the
+50M truth titles of C5; this one takes seconds.  Same recipe and parameters, different random draws: the workload of a
+given seed is NOT the round-2 workload of that seed.
+
+Measured at N = 500k (seed 20260101; SURVEY.md 8d targets in brackets): see
 tests/test_host_cpu.py::test_synthetic_workload_acceptance_at_c2_truth_size.
 
 `make_workload` returns everything both kernels consume, built the way MatchMaker.__init__ /
@@ -22,13 +27,16 @@ column order fixed to ascending tri-gram code instead of Python-set order:
     q_rowptr / q_cols / q_maxint                 query rows (ascending column ids) and max_intersection_possible
     q_enc, q_len, t_enc, t_len, t_counts         encoded titles (uint8[*, 255]), lengths, truth word counts
 """
+import ctypes
+import hashlib
+import os
+import subprocess
 import math
 from types import SimpleNamespace
 
 import numpy as np
 
 from .feature_engineering import ALLOWED_CHARACTERS, MAX_CHARACTERS_ALLOWED_IN_THE_TITLE, NUMBER_OF_WORDS_FEATURES
-from .match_maker import sequential_sums
 
 DEFAULT_SEED = 20260101
 _BASE = len(ALLOWED_CHARACTERS)  # 38 codes: '-'=0 (fill), ' '=1, a-z=2..27, 0-9=28..37
@@ -49,15 +57,6 @@ _KEYBOARD_ROWS = ("1234567890", "qwertyuiop", "asdfghjkl", "zxcvbnm")
 
 def _codes(text):
     return np.array([ALLOWED_CHARACTERS.index(ch) for ch in text], dtype=np.uint8)
-
-
-def _ragged_arange(lengths):
-    """[0..l0), [0..l1), ... concatenated, plus the row id of every element."""
-    lengths = np.asarray(lengths, dtype=np.int64)
-    total = int(lengths.sum())
-    starts = np.cumsum(lengths) - lengths
-    rows = np.repeat(np.arange(lengths.shape[0], dtype=np.int64), lengths)
-    return np.arange(total, dtype=np.int64) - starts[rows], rows
 
 
 class _Vocabulary:
@@ -110,52 +109,108 @@ class _Vocabulary:
                                            self.size - len(_SUFFIXES) - 1)
 
 
-def _make_titles(rng, vocabulary, count):
-    """Titles as ragged arrays of words -> (flat codes, offsets, word ids per title as (flat, offsets), word table).
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_native = None
 
-    Word ids index the returned word table = the vocabulary's words followed by this call's hapaxes."""
-    n_words = np.clip(1 + rng.poisson(2.5, count), 1, 20).astype(np.int64)
-    has_suffix = rng.rand(count) < SUFFIX_SHARE
-    body_words = np.where(has_suffix & (n_words > 1), n_words - 1, n_words)
-    position, row = _ragged_arange(n_words)
-    word_ids = vocabulary.sample(rng, position.shape[0])
-    suffix_choice = rng.choice(len(_SUFFIXES), size=count, p=_SUFFIX_WEIGHTS)
-    is_suffix_slot = has_suffix[row] & (n_words[row] > 1) & (position == body_words[row])
-    word_ids = np.where(is_suffix_slot, suffix_choice[row], word_ids)
-    # hapaxes: fresh words of 4..20 uniformly random characters, appended to the word table
-    hapax_slot = (rng.rand(position.shape[0]) < HAPAX_FRACTION) & ~is_suffix_slot
-    n_hapax = int(hapax_slot.sum())
-    width = vocabulary.chars.shape[1]
-    hapax_lengths = np.clip(np.rint(rng.lognormal(1.7, 0.45, n_hapax)), 4, width).astype(np.int64)
-    hapax_chars = np.where(rng.rand(n_hapax, width) < HAPAX_DIGIT_SHARE, rng.randint(28, 38, (n_hapax, width)),
-                           rng.randint(2, 28, (n_hapax, width))).astype(np.uint8)
-    hapax_chars[np.arange(width)[None, :] >= hapax_lengths[:, None]] = 0
-    word_ids = word_ids.copy()
-    word_ids[hapax_slot] = vocabulary.size + np.arange(n_hapax)
-    table_chars = np.concatenate([vocabulary.chars, hapax_chars])
-    table_lengths = np.concatenate([vocabulary.lengths, hapax_lengths])
-    # keep the leading words that fit in 255 characters
-    lengths = table_lengths[word_ids]
-    starts = np.cumsum(n_words) - n_words
-    running = np.cumsum(lengths + 1)
-    before = np.concatenate(([0], running))[starts]
-    end_in_title = running - before[row] - 1  # position of the word's last char + 1 within the title
-    fits = end_in_title <= MAX_CHARACTERS_ALLOWED_IN_THE_TITLE
-    word_ids, row, lengths = word_ids[fits], row[fits], lengths[fits]
-    n_words = np.bincount(row, minlength=count).astype(np.int64)
-    word_offsets = np.concatenate(([0], np.cumsum(n_words)))
-    first_of_title = np.zeros(word_ids.shape[0], dtype=bool)
-    first_of_title[word_offsets[:-1]] = True
-    # destination of every word inside the flat character array (one space before every non-first word)
-    piece = lengths + (~first_of_title)
-    piece_start = np.cumsum(piece) - piece
-    title_lengths = np.bincount(row, weights=piece, minlength=count).astype(np.int64)
-    offsets = np.concatenate(([0], np.cumsum(title_lengths)))
-    flat = np.full(int(offsets[-1]), _SPACE, dtype=np.uint8)
-    within, word_row = _ragged_arange(lengths)
-    destination = (piece_start + (~first_of_title))[word_row] + within
-    flat[destination] = table_chars[word_ids[word_row], within]
-    return flat, offsets, word_ids, word_offsets, table_chars
+
+def _native_source():
+    return os.path.join(_HERE, "csrc", "ds_synth.cpp")
+
+
+def build_native(force=False):
+    """g++ csrc/ds_synth.cpp -> libdoppel_synth.so next to this file; rebuilt when the source's hash changes."""
+    target = os.path.join(_HERE, "libdoppel_synth.so")
+    with open(_native_source(), "rb") as handle:
+        wanted = hashlib.sha256(handle.read()).hexdigest()[:16]
+    stamp = target + ".id"
+    if not force and os.path.exists(target) and os.path.exists(stamp) and open(stamp).read().strip() == wanted:
+        return target
+    scratch = f"{target}.{os.getpid()}.tmp"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", _native_source(), "-o", scratch])
+    os.replace(scratch, target)
+    with open(stamp + f".{os.getpid()}", "w") as handle:
+        handle.write(wanted)
+    os.replace(stamp + f".{os.getpid()}", stamp)
+    return target
+
+
+def _generator():
+    global _native
+    if _native is None:
+        handle = ctypes.CDLL(build_native())
+        p, i64, u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64
+        handle.synth_titles.argtypes = [u64, u64, i64, i64, p, p, i64, i64, p, p, p, p, p, ctypes.c_int, p, p, p]
+        handle.synth_queries.argtypes = [u64, i64, p, p, p, p, p, p, i64, i64, p, p, p, p, p, ctypes.c_int, p, p, p]
+        _native = handle
+    return _native
+
+
+def host_threads():
+    """Threads of the native generator (the product library reads DS_HOST_THREADS itself)."""
+    wanted = int(os.environ.get("DS_HOST_THREADS", "0") or 0)
+    return wanted if wanted >= 1 else min(32, len(os.sched_getaffinity(0)))
+
+
+def _ptr(array):
+    return ctypes.c_void_p(array.ctypes.data) if array is not None else ctypes.c_void_p(0)
+
+
+def _tables(vocabulary):
+    """The distributions of the recipe as cumulative tables (the native side only searches them)."""
+    # words per title: clip(1 + Poisson(2.5), 1, 20)
+    pmf = np.array([math.exp(-2.5) * 2.5 ** k / math.factorial(k) for k in range(19)])
+    words = np.minimum(np.concatenate((np.cumsum(pmf), [1.0])), 1.0)
+    # hapax length: clip(rint(lognormal(1.7, 0.45)), 4, 20)
+    def below(x):
+        return 0.5 * (1.0 + math.erf((math.log(x) - 1.7) / (0.45 * math.sqrt(2.0))))
+    hapax = np.array([below(length + 0.5) for length in range(4, 20)] + [1.0])
+    suffix = np.cumsum(_SUFFIX_WEIGHTS / _SUFFIX_WEIGHTS.sum())
+    suffix[-1] = 1.0
+    shares = np.array([SUFFIX_SHARE, HAPAX_FRACTION, HAPAX_DIGIT_SHARE], dtype=np.float64)
+    neighbours = np.zeros((256, 2), dtype=np.uint8)
+    for row in _KEYBOARD_ROWS:
+        for at, character in enumerate(row):
+            code = ALLOWED_CHARACTERS.index(character)
+            if at > 0:
+                neighbours[code, 0] = ALLOWED_CHARACTERS.index(row[at - 1])
+            if at + 1 < len(row):
+                neighbours[code, 1] = ALLOWED_CHARACTERS.index(row[at + 1])
+    return dict(word_chars=np.ascontiguousarray(vocabulary.chars, dtype=np.uint8),
+                word_lengths=np.ascontiguousarray(vocabulary.lengths, dtype=np.uint8),
+                zipf=np.ascontiguousarray(vocabulary.cumulative, dtype=np.float64),
+                words=np.ascontiguousarray(words), suffix=np.ascontiguousarray(suffix),
+                hapax=np.ascontiguousarray(hapax), shares=shares, neighbours=neighbours)
+
+
+def _vocabulary_arguments(tables):
+    return (_ptr(tables["word_chars"]), _ptr(tables["word_lengths"]), tables["word_chars"].shape[0], len(_SUFFIXES),
+            _ptr(tables["zipf"]), _ptr(tables["words"]), _ptr(tables["suffix"]), _ptr(tables["hapax"]),
+            _ptr(tables["shares"]), host_threads())
+
+
+def _make_titles(tables, seed, count, purpose=0):
+    """`count` fresh titles of stream (seed, purpose) -> (flat codes, offsets)."""
+    lengths = np.zeros(count, dtype=np.int32)
+    arguments = (seed, purpose, 0, count) + _vocabulary_arguments(tables)
+    assert _generator().synth_titles(*arguments, _ptr(lengths), None, None) == 0
+    offsets = np.zeros(count + 1, dtype=np.int64)
+    np.cumsum(lengths, out=offsets[1:])
+    flat = np.zeros(max(1, int(offsets[-1])), dtype=np.uint8)
+    assert _generator().synth_titles(*arguments, None, _ptr(offsets), _ptr(flat)) == 0
+    return flat[:int(offsets[-1])], offsets
+
+
+def _make_queries(tables, seed, source, t_flat, t_off):
+    count = source.shape[0]
+    lengths = np.zeros(count, dtype=np.int32)
+    arguments = (seed, count, _ptr(source), _ptr(t_flat), _ptr(t_off), _ptr(tables["neighbours"])) + \
+        _vocabulary_arguments(tables)
+    assert _generator().synth_queries(*arguments, _ptr(lengths), None, None) == 0
+    offsets = np.zeros(count + 1, dtype=np.int64)
+    np.cumsum(lengths, out=offsets[1:])
+    flat = np.zeros(max(1, int(offsets[-1])), dtype=np.uint8)
+    assert _generator().synth_queries(*arguments, None, _ptr(offsets), _ptr(flat)) == 0
+    return flat[:int(offsets[-1])], offsets
 
 
 def _to_strings(flat, offsets):
@@ -163,41 +218,6 @@ def _to_strings(flat, offsets):
     table = np.frombuffer(text.encode("ascii"), dtype=np.uint8)
     raw = table[flat].tobytes().decode("ascii")
     return [raw[offsets[i]:offsets[i + 1]] for i in range(offsets.shape[0] - 1)]
-
-
-def _neighbour(rng, character):
-    for row in _KEYBOARD_ROWS:
-        at = row.find(character)
-        if at >= 0:
-            candidates = [row[i] for i in (at - 1, at + 1) if 0 <= i < len(row)]
-            return candidates[rng.randint(len(candidates))]
-    return "e"
-
-
-def _misspell(rng, title):
-    """1-2 edits: delete / insert neighbour / replace with neighbour / insert space / remove space / swap words."""
-    for _ in range(1 + int(rng.rand() < 0.4)):
-        kind = rng.randint(6)
-        at = rng.randint(len(title))
-        if kind == 0 and len(title) > 4:
-            title = title[:at] + title[at + 1:]
-        elif kind == 1:
-            title = title[:at] + _neighbour(rng, title[at]) + title[at:]
-        elif kind == 2 and title[at] != " ":
-            title = title[:at] + _neighbour(rng, title[at]) + title[at + 1:]
-        elif kind == 3 and 0 < at < len(title) - 1 and title[at] != " " and title[at - 1] != " ":
-            title = title[:at] + " " + title[at:]
-        elif kind == 4 and " " in title:
-            spaces = [i for i, ch in enumerate(title) if ch == " "]
-            cut = spaces[rng.randint(len(spaces))]
-            title = title[:cut] + title[cut + 1:]
-        elif kind == 5 and " " in title:
-            words = title.split(" ")
-            i = rng.randint(len(words) - 1)
-            words[i], words[i + 1] = words[i + 1], words[i]
-            title = " ".join(words)
-    title = " ".join(title.split())[:MAX_CHARACTERS_ALLOWED_IN_THE_TITLE].strip()
-    return title if len(title) >= 3 else title.rjust(3, "0")  # common.py:34-38
 
 
 def _from_strings(titles):
@@ -210,104 +230,73 @@ def _from_strings(titles):
     return flat, offsets
 
 
-def _tri_grams(flat, offsets):
-    """Unique (title, tri-gram code) pairs, sorted by title then code (common.py:150-151 get_n_grams)."""
-    lengths = np.diff(offsets)
-    n_grams = np.maximum(lengths - 2, 0)
-    within, row = _ragged_arange(n_grams)
-    at = offsets[:-1][row] + within
-    codes = (flat[at].astype(np.int64) * _BASE + flat[at + 1]) * _BASE + flat[at + 2]
-    keys = np.unique(row * (_BASE ** 3) + codes)
-    return keys // (_BASE ** 3), keys % (_BASE ** 3)
-
-
-def _encode(flat, offsets):
+def encode_collection(flat, offsets, code_of=None, stride=MAX_CHARACTERS_ALLOWED_IN_THE_TITLE):
+    """encode_title for a whole collection through the product's ds_encode_titles: (uint8[n, stride], uint8[n])."""
+    from . import _lib
     count = offsets.shape[0] - 1
-    lengths = np.diff(offsets)
-    enc = np.zeros((count, MAX_CHARACTERS_ALLOWED_IN_THE_TITLE), dtype=np.uint8)
-    within, row = _ragged_arange(lengths)
-    enc[row, within] = flat
-    return enc, lengths.astype(np.uint8)
+    enc = np.empty((count, stride), dtype=np.uint8)
+    lengths = np.empty(count, dtype=np.uint8)
+    flat = np.ascontiguousarray(flat, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    _lib.check(_lib.lib().ds_encode_titles(_ptr(flat), _ptr(offsets), count, _ptr(code_of), stride, _ptr(enc),
+                                           _ptr(lengths)), "ds_encode_titles")
+    return enc, lengths
+
+
+def truth_word_counts(flat, offsets, separators=(_SPACE,)):
+    """get_truth_words_counts for a whole collection through the product's ds_truth_word_counts: uint32[n, 15]."""
+    from . import _lib
+    count = offsets.shape[0] - 1
+    out = np.empty((count, NUMBER_OF_WORDS_FEATURES), dtype=np.uint32)
+    table = np.zeros(256, dtype=np.uint8)
+    table[list(separators)] = 1
+    flat = np.ascontiguousarray(flat, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    _lib.check(_lib.lib().ds_truth_word_counts(_ptr(flat), _ptr(offsets), count, _ptr(table), _ptr(out)),
+               "ds_truth_word_counts")
+    return out
+
+
+def make_truth(n_truth, seed=DEFAULT_SEED, vocabulary_size=None):
+    """The truth side of a workload (depends on `seed` only, identical on every rank)."""
+    rng = np.random.RandomState(seed)
+    vocabulary = _Vocabulary(rng, vocabulary_size or max(20000, n_truth // 25))
+    tables = _tables(vocabulary)
+    t_flat, t_off = _make_titles(tables, seed, n_truth)
+    return tables, t_flat, t_off
 
 
 def make_workload(n_truth, n_queries, seed=DEFAULT_SEED, vocabulary_size=None, query_seed=None):
     """Truth titles depend on `seed` only (identical on every rank); queries on `query_seed` (default seed + 1)."""
-    rng = np.random.RandomState(seed)
-    vocabulary = _Vocabulary(rng, vocabulary_size or max(20000, n_truth // 25))
-    t_flat, t_off, t_words, t_word_off, t_word_table = _make_titles(rng, vocabulary, n_truth)
+    from . import _lib
+    from .match_maker import NativeProblem
+    tables, t_flat, t_off = make_truth(n_truth, seed, vocabulary_size)
 
-    # ---- queries: 60 % misspelled truth titles, 40 % fresh titles
-    title_id = rng.permutation(n_truth).astype(np.int64)
-    rng = np.random.RandomState(seed + 1 if query_seed is None else query_seed)
+    # ---- queries: 60 % misspelled truth titles, 40 % fresh titles, in random order
+    query_seed = seed + 1 if query_seed is None else query_seed
+    rng = np.random.RandomState(query_seed)
     n_edited = int(round(0.6 * n_queries))
-    source = rng.randint(0, n_truth, n_edited)
-    truth_strings_needed = _to_strings(
-        np.concatenate([t_flat[t_off[s]:t_off[s + 1]] for s in source]) if n_edited else np.zeros(0, np.uint8),
-        np.concatenate(([0], np.cumsum(t_off[source + 1] - t_off[source]))) if n_edited else np.zeros(1, np.int64))
-    edited = [_misspell(rng, title) for title in truth_strings_needed]
-    f_flat, f_off, _, _, _ = _make_titles(rng, vocabulary, n_queries - n_edited)
-    fresh = _to_strings(f_flat, f_off)
-    order = rng.permutation(n_queries)
-    query_strings = [None] * n_queries
-    actual = np.full(n_queries, -1, dtype=np.int64)  # truth row the query was derived from (-1 = none)
-    for slot, title in zip(order[:n_edited], edited):
-        query_strings[slot] = title
-    actual[order[:n_edited]] = source
-    for slot, title in zip(order[n_edited:], fresh):
-        query_strings[slot] = title
-    q_flat, q_off = _from_strings(query_strings)
+    actual = np.full(n_queries, -1, dtype=np.int64)   # truth row the query was derived from (-1 = none)
+    actual[rng.permutation(n_queries)[:n_edited]] = rng.randint(0, n_truth, n_edited)
+    q_flat, q_off = _make_queries(tables, query_seed, actual, t_flat, t_off)
 
-    # ---- MatchMaker.__init__ (match_maker.py:91-107) with ascending tri-gram codes as the column order
-    t_row, t_code = _tri_grams(t_flat, t_off)
-    q_row, q_code = _tri_grams(q_flat, q_off)
-    vocabulary_codes = np.union1d(t_code, q_code)
-    n_columns = vocabulary_codes.shape[0]
-    t_col = np.searchsorted(vocabulary_codes, t_code)
-    q_col = np.searchsorted(vocabulary_codes, q_code)
-    df = np.bincount(t_col, minlength=n_columns)
-    idf64 = np.full(n_columns, 0.0)
-    seen = df > 0
-    idf64[seen] = [math.log(n_truth / int(c)) for c in df[seen]]        # match_maker.py:135-139
-    idf64[~seen] = idf64[seen].max()                                     # :95, :151
-    idf32 = idf64.astype(np.float32)
-
-    t_counts_per_row = np.bincount(t_row, minlength=n_truth)
-    sums32 = sequential_sums(idf32[t_col], t_counts_per_row, np.float32)  # :174
-    keep = idf32[t_col] != 0
-    order_by_column = np.argsort(t_col[keep], kind="stable")
-    truth_idx = t_row[keep][order_by_column].astype(np.int32)
-    rowptr = np.concatenate(([0], np.cumsum(np.bincount(t_col[keep], minlength=n_columns)))).astype(np.int64)
-
-    keep_q = idf32[q_col] != 0
-    q_row, q_col = q_row[keep_q], q_col[keep_q]
-    q_counts = np.bincount(q_row, minlength=n_queries)
-    q_rowptr = np.concatenate(([0], np.cumsum(q_counts))).astype(np.int64)
-    q_maxint = sequential_sums(idf64[q_col], q_counts, np.float64)       # :197
+    # ---- MatchMaker.__init__ (match_maker.py:91-107) by the native index build; columns ascend with the tri-gram code
+    problem = NativeProblem.from_flat(t_flat, t_off, q_flat, q_off, 3)
+    arrays = problem.arrays(copy=False)   # views of the handle's memory: the workload keeps the handle alive
 
     # ---- encoded titles and truth word counts (feature_engineering.py:298-319)
-    t_enc, t_len = _encode(t_flat, t_off)
-    q_enc, q_len = _encode(q_flat, q_off)
-    word_row = np.repeat(np.arange(n_truth, dtype=np.int64), np.diff(t_word_off))
-    # the reference counts words as strings (common.py:140-142): two hapaxes spelled alike are one word
-    used, t_words = np.unique(t_words, return_inverse=True)
-    spelled = np.ascontiguousarray(t_word_table[used]).view(np.dtype((np.void, t_word_table.shape[1]))).reshape(-1)
-    _, canonical = np.unique(spelled, return_inverse=True)
-    t_words = canonical[t_words]
-    n_distinct_words = int(canonical.max()) + 1 if canonical.shape[0] else 0
-    pairs = np.unique(word_row * n_distinct_words + t_words)
-    word_df = np.bincount(pairs % n_distinct_words, minlength=n_distinct_words)
-    slot, _ = _ragged_arange(np.diff(t_word_off))
-    first = slot < NUMBER_OF_WORDS_FEATURES
-    t_counts = np.zeros((n_truth, NUMBER_OF_WORDS_FEATURES), dtype=np.uint32)
-    t_counts[word_row[first], slot[first]] = word_df[t_words[first]]
+    t_enc, t_len = encode_collection(t_flat, t_off)
+    q_enc, q_len = encode_collection(q_flat, q_off)
+    t_counts = truth_word_counts(t_flat, t_off)
+    title_id = np.random.RandomState(seed + 2).permutation(n_truth).astype(np.int64)
 
     return SimpleNamespace(
-        n_truth=n_truth, n_queries=n_queries, n_columns=n_columns, seed=seed,
-        rowptr=rowptr, truth_idx=truth_idx, idf32=idf32, idf64=idf64, sums32=sums32,
-        q_rowptr=q_rowptr, q_cols=q_col.astype(np.int32), q_maxint=q_maxint,
+        n_truth=n_truth, n_queries=n_queries, n_columns=int(arrays["idf32"].shape[0]), seed=seed,
+        rowptr=arrays["rowptr"], truth_idx=arrays["truth_idx"], idf32=arrays["idf32"], idf64=arrays["idf64"],
+        sums32=arrays["sums32"], q_rowptr=arrays["q_rowptr"], q_cols=arrays["q_cols"], q_maxint=arrays["q_maxint"],
         t_enc=t_enc, t_len=t_len, t_counts=t_counts, q_enc=q_enc, q_len=q_len,
         title_id=title_id, actual_row=actual,
-        t_flat=t_flat, t_off=t_off, q_flat=q_flat, q_off=q_off)
+        t_flat=t_flat, t_off=t_off, q_flat=q_flat, q_off=q_off, problem=problem)
 
 
 def workload_statistics(w, positive_sample=0):

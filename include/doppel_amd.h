@@ -56,7 +56,9 @@ int ds_device_name(int device, char *name, size_t capacity);
 /* ---- truth index:  MatchMaker.__init__ product (match_maker.py:99-107) ------------------------------------------ */
 /* rowptr[V+1], truth_idx[nnz]: the V x N inverted index of match_maker.py:122-133 in CSR form (row g = n-gram
  * column g, entries = ascending truth row indexes).  idf32[V] = the constant per-posting value of :130.
- * sums32[N] = sums_matrix_truth of :102,174.  The per-posting value array of the reference is not stored. */
+ * sums32[N] = sums_matrix_truth of :102,174.  The per-posting value array of the reference is not stored.
+ * The host part (tiling, signatures, duplicate ranks) runs on DS_HOST_THREADS threads (default: the CPUs of the
+ * process, at most 32); DS_BUILD_LOG=1 prints its phase times on stderr. */
 int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float *idf32, const float *sums32,
                     int64_t V, int64_t N, int device, ds_index **out);
 void ds_index_destroy(ds_index *index);
@@ -65,6 +67,11 @@ void ds_index_destroy(ds_index *index);
  * LARGEST ROW INDEXES at or above its threshold (match_maker.py:71): a row of rank >= k can never be returned. */
 int ds_index_duplicate_ranks(const int64_t *rowptr, const int32_t *truth_idx, const float *sums32, int64_t V, int64_t N,
                              uint16_t *rank_out);
+/* Host-only, for tests: FNV-1a digests of the arrays ds_index_create uploads, built for tiles of `tile_rows` rows.
+ * digest[0..5] = list pointers, postings, per-posting info, row records, tile minima, signature columns; [6] = posting
+ * quads; [7] = 1 when the index would be served by the literal kernel alone.  Must not depend on DS_HOST_THREADS. */
+int ds_index_image_digest(const int64_t *rowptr, const int32_t *truth_idx, const float *idf32, const float *sums32,
+                          int64_t V, int64_t N, int64_t tile_rows, uint64_t digest[8]);
 /* Diagnostics switches of an index.  "count_bytes" (0 / 1): the next ds_jaccard_topk* calls run the instantiation of
  * the fast kernel that also counts the bytes it requests from global memory (reported by ds_jaccard_sync, stats[15]);
  * same work, same results, about 3 % slower -- bench.py runs it once outside the timed region for its roofline. */
@@ -164,7 +171,8 @@ int ds_select_matches_device(const int32_t *d_pair_q, const int32_t *d_pair_t, c
  * get_n_grams / get_n_grams_counter (doppelspeller/common.py:145-151): from the transformed titles (byte strings,
  * concatenated, offsets[n + 1]) to the arrays ds_index_create and ds_jaccard_topk take.  Host code.  Column ids
  * ascend with the n-gram's byte string and a title's float32 idf sum runs in first-occurrence order of its n-grams
- * (the reference leaves both to Python's set iteration order).  The arrays belong to the handle. */
+ * (the reference leaves both to Python's set iteration order).  The arrays belong to the handle.  Threaded over title
+ * ranges (DS_HOST_THREADS, default: the CPUs of the process, at most 32); the result does not depend on the count. */
 int ds_problem_create(const uint8_t *truth_chars, const int64_t *truth_offsets, int64_t n_truth,
                       const uint8_t *query_chars, const int64_t *query_offsets, int64_t n_queries, int32_t n_gram,
                       ds_problem **out);
@@ -175,6 +183,18 @@ int ds_problem_info(const ds_problem *problem, int64_t info[8]);
 int ds_problem_arrays(const ds_problem *problem, const uint32_t **vocabulary, const float **idf32, const double **idf64,
                       const int64_t **rowptr, const int32_t **truth_idx, const float **sums32, const int64_t **q_rowptr,
                       const int32_t **q_cols, const double **q_maxint);
+
+/* The encoders of the features' inputs for whole collections, host code, threaded:
+ * ds_encode_titles  = FeatureEngineering.encode_title (doppelspeller/feature_engineering.py:298-307) per title:
+ *   out_enc[t*stride ..) = the title's characters mapped through code_of[256] (NULL: bytes as they are), 0-padded to
+ *   `stride` (255 in the reference, settings.py:68); out_len[t] = its number of characters (predict.py:195-197);
+ * ds_truth_word_counts = FeatureEngineering.get_truth_words_counts (:309-319) per title over the counter of
+ *   common.py:140-142: out_counts[t*DS_WORDS + j] = the number of truth titles holding the j-th word of title t (a word
+ *   repeated inside one title counts once), 0-padded.  separator[256] != 0 marks the bytes str.split() splits on. */
+int ds_encode_titles(const uint8_t *chars, const int64_t *offsets, int64_t n, const uint8_t *code_of, int64_t stride,
+                     uint8_t *out_enc, uint8_t *out_len);
+int ds_truth_word_counts(const uint8_t *chars, const int64_t *offsets, int64_t n, const uint8_t *separator,
+                         uint32_t *out_counts);
 
 /* transform_title (doppelspeller/common.py:20-47) for n titles whose Unicode step (NFD + ASCII encoding, Python's
  * unicodedata) is already done: lower case, '-' -> ' ', keep [a-zA-Z0-9\s], ' +' -> ' ', strip, cut to max_characters

@@ -93,3 +93,105 @@ def test_duplicate_ranks_against_a_dictionary():
         seen[key] = expected[t] + 1
     assert np.array_equal(ranks, expected)
     assert expected.max() >= 10   # the workload does contain long runs of twins
+
+
+# ---- round 3: the host side is threaded (DS_HOST_THREADS); nothing may depend on the thread count ----------------------
+def _digest(w, tile_rows):
+    from doppel_speller_amd import _lib
+    digest = np.zeros(8, dtype=np.uint64)
+    _lib.check(_lib.lib().ds_index_image_digest(_lib.pointer(w.rowptr), _lib.pointer(w.truth_idx), _lib.pointer(w.idf32),
+                                                _lib.pointer(w.sums32), w.n_columns, w.n_truth, tile_rows,
+                                                _lib.pointer(digest)), "ds_index_image_digest")
+    return digest
+
+
+@pytest.mark.parametrize("tile_rows", [12288, 28672, 64])
+def test_index_image_does_not_depend_on_the_thread_count(monkeypatch, tile_rows):
+    """The arrays ds_index_create uploads (list pointers, parity-grouped postings, per-posting info, row records with
+    signatures and duplicate ranks, tile minima) digested for 1, 3 and 8 build threads."""
+    from doppel_speller_amd import synth
+    w = synth.make_workload(40_000, 10, seed=11)
+    digests = []
+    for threads in (1, 3, 8):
+        monkeypatch.setenv("DS_HOST_THREADS", str(threads))
+        digests.append(_digest(w, tile_rows))
+    assert np.array_equal(digests[0], digests[1]) and np.array_equal(digests[0], digests[2])
+    assert digests[0][6] > 0 and digests[0][7] == 0
+
+
+def test_index_image_rejects_bad_posting_lists(monkeypatch):
+    import doppel_speller_amd as ds
+    from doppel_speller_amd import synth
+    w = synth.make_workload(2_000, 10, seed=11)
+    for threads in (1, 4):
+        monkeypatch.setenv("DS_HOST_THREADS", str(threads))
+        for value in (-1, w.n_truth, None):
+            broken = w.truth_idx.copy()
+            column = int(np.argmax(np.diff(w.rowptr)))
+            at = int(w.rowptr[column]) + 3
+            broken[at] = broken[at - 1] if value is None else value     # not strictly ascending / outside [0, N)
+            saved, w.truth_idx = w.truth_idx, broken
+            with pytest.raises(ds.DoppelError, match="not strictly ascending"):
+                _digest(w, 64)
+            w.truth_idx = saved
+
+
+def test_problem_create_does_not_depend_on_the_thread_count(monkeypatch):
+    from doppel_speller_amd import synth
+    from doppel_speller_amd.match_maker import NativeProblem
+    w = synth.make_workload(20_000, 3_000, seed=12)
+    results = []
+    for threads in (1, 5):
+        monkeypatch.setenv("DS_HOST_THREADS", str(threads))
+        results.append(NativeProblem.from_flat(w.t_flat, w.t_off, w.q_flat, w.q_off, 3).arrays())
+    for name, array in results[0].items():
+        assert np.array_equal(array.view(np.uint8), results[1][name].view(np.uint8)), name
+    # and a binary alphabet (all 256 byte values: the dense key space is 2^24 tri-grams) still builds
+    rng = np.random.RandomState(1)
+    chars = rng.randint(0, 256, 5000).astype(np.uint8)
+    offsets = np.arange(0, 5001, 50, dtype=np.int64)
+    problem = NativeProblem.from_flat(chars, offsets, chars[:500], offsets[:11], 3)
+    keys = problem.arrays()["vocabulary_keys"]
+    assert (np.diff(keys.astype(np.int64)) > 0).all() and problem.n_columns > 4000
+
+
+def test_generator_does_not_depend_on_the_thread_count(monkeypatch):
+    from doppel_speller_amd import synth
+    runs = []
+    for threads in (1, 6):
+        monkeypatch.setenv("DS_HOST_THREADS", str(threads))
+        w = synth.make_workload(5_000, 2_000, seed=13)
+        runs.append((w.t_flat.copy(), w.t_off.copy(), w.q_flat.copy(), w.q_off.copy(), w.t_counts.copy(), w.t_enc.copy()))
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
+    lengths = np.diff(runs[0][3])
+    assert lengths.min() >= 3 and lengths.max() <= 255          # common.py:28-38: at most 255, '0'-padded to a tri-gram
+
+
+def test_encoders_for_whole_collections_against_the_per_title_functions(monkeypatch):
+    """ds_encode_titles / ds_truth_word_counts (row a7, native + threaded) against encode_title /
+    get_truth_words_counts over collections.Counter (feature_engineering.py:298-319, common.py:140-142)."""
+    from collections import Counter
+    from doppel_speller_amd import synth
+    from doppel_speller_amd.feature_engineering import ALLOWED_CHARACTERS, encode_title, get_truth_words_counts
+    w = synth.make_workload(6_000, 10, seed=14)
+    titles = synth._to_strings(w.t_flat, w.t_off)
+    titles[5] = "bv bv limited bv"                              # a word repeated inside a title counts once
+    titles[6] = " ".join(f"w{i}" for i in range(20))            # more than 15 words
+    titles[7] = "   spaced   out  "                             # runs of separators: str.split() semantics
+    titles[8] = ""
+    counter = Counter(word for title in titles for word in set(title.split()))   # common.py:140-142
+    code_of = np.zeros(256, dtype=np.uint8)
+    for code, character in enumerate(ALLOWED_CHARACTERS):
+        code_of[ord(character)] = code
+    raw = np.frombuffer("".join(titles).encode("ascii"), dtype=np.uint8)
+    offsets = np.concatenate(([0], np.cumsum([len(t) for t in titles]))).astype(np.int64)
+    for threads in (1, 7):
+        monkeypatch.setenv("DS_HOST_THREADS", str(threads))
+        enc, lengths = synth.encode_collection(raw, offsets, code_of)
+        counts = synth.truth_word_counts(raw, offsets, separators=[ord(c) for c in " \t\n\r\x0b\x0c\x1c\x1d\x1e\x1f"])
+        for row in list(range(12)) + list(range(12, len(titles), 97)):
+            assert np.array_equal(enc[row], encode_title(titles[row])), row
+            assert lengths[row] == len(titles[row])
+            assert np.array_equal(counts[row], get_truth_words_counts(titles[row], counter)), (row, titles[row])
+    assert counts[5, 0] == counter["bv"] and counts[5, 1] == counter["bv"] and counts[5, 4] == 0
