@@ -29,8 +29,14 @@ Extra objects on the line:
                 file was measured on this build and workload; `bound_model` = the kernel's shares of VALU issue, LDS and HBM time from the same
                 counters; `speedup_over_reference_hbm_floor` = the bytes the REFERENCE's algorithm would read
                  / launch duration / 8 TB/s -- above 1 because the kernel skips most of them.
+  roofline_features  ds_construct_features_kernel against its own ceilings (VALU integer, not HBM).
   cpu_baseline  the oracle (C restatement of the reference, OpenMP) timed on a bounded sample of the same workload
-                (rank 0, N=1 only), best of a thread sweep.
+                (rank 0, N=1 only), thread count chosen from pilots of >= 2 s each.
+
+With N > 1 rank 0 generates the WHOLE workload once (all queries of all ranks: one vocabulary, as one MatchMaker over
+all data has) and publishes it under /dev/shm; every rank maps it and takes its contiguous query shard.  RCCL is
+mandatory then: if the communicator cannot be created the job prints the reason and exits non-zero (the host gather is
+for rehearsals: --host-communicator, or --allow-host-fallback / DS_BENCH_SAME_DEVICE=1 on a one-GPU box).
 """
 import argparse
 import json
@@ -107,39 +113,50 @@ def cpu_baseline(workload, k, budget_seconds):
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1
 
-    # thread sweep on small pilots (the per-thread N-vectors of the reference's algorithm thrash the caches when every
-    # hardware thread runs one): 1 thread, then 32 / 64 / ... / all
-    sweep = {}
+    # thread sweep on pilots of >= 2 s each (long enough to leave the caches: the per-thread N-vectors of the
+    # reference's algorithm thrash them when every hardware thread runs one): 1 thread, then 8 / 16 / ... / all
+    sweep, pilots = {}, {}
     candidates = sorted({1, cores} | {t for t in (8, 16, 32, 64, 128) if t < cores})
+    spent = 0.0
     for threads in candidates:
-        pilot = min(workload.n_queries, max(4 * threads, 128))  # enough queries per thread for a stable ranking
+        pilot = min(workload.n_queries, max(4 * threads, 64))
         tj, tf = run(pilot, threads)
+        while tj + tf < 2.0 and pilot < workload.n_queries:      # grow the pilot until it runs for two seconds
+            pilot = min(workload.n_queries, int(pilot * max(2.0, 2.5 / max(tj + tf, 1e-3))))
+            tj, tf = run(pilot, threads)
         sweep[threads] = pilot * k / (tj + tf)
-        if tj + tf > budget_seconds / 3:
+        pilots[threads] = {"queries": pilot, "seconds": tj + tf}
+        spent += tj + tf
+        if spent > 0.6 * budget_seconds:
             break
     best = max(sweep, key=sweep.get)
-    n_sample = int(min(workload.n_queries, max(2 * best, 0.5 * budget_seconds * sweep[best] / k)))
+    n_sample = int(min(workload.n_queries, max(pilots[best]["queries"], 0.5 * budget_seconds * sweep[best] / k)))
     tj, tf = run(n_sample, best)
     oracle.set_num_threads(cores)
     return {"value": n_sample * k / (tj + tf), "unit": "candidate-pairs/s", "cores": best, "kind": "port",
             "sample": f"first {n_sample} queries of the workload x {workload.n_truth} truth titles, top-{k} "
                       f"(jaccard+topk {tj:.2f}s, features {tf:.2f}s on {best} OpenMP threads)",
             "cpu": cpu_model(), "host_threads": cores,
+            "pilot_same_threads": {"pairs_per_s": round(sweep[best], 1), **pilots[best]},
             "thread_sweep_pairs_per_s": {str(t): round(v, 1) for t, v in sweep.items()},
+            "thread_sweep_pilots": {str(t): v for t, v in pilots.items()},
             "queries_per_s": n_sample / tj, "feature_pairs_per_s": n_sample * k / tf}
 
 
 def resolve_config(name, world, queries=None, truth=None, k=None):
-    """(queries per GPU, truth titles, k, "weak" | "strong", BASELINE.json's text, overridden?) of a configuration on
-    `world` GPUs.  "per_gpu" configurations keep the per-GPU batch fixed (weak scaling); "total" ones divide a fixed
-    number of queries over the GPUs (strong scaling: C4 = 8M in all, C5 = 1M in all)."""
+    """(queries in the whole job, truth titles, k, "weak" | "strong", BASELINE.json's text, overridden?) of a
+    configuration on `world` GPUs.  "per_gpu" configurations keep the per-GPU batch fixed (weak scaling); "total" ones
+    divide a fixed number of queries over the GPUs (strong scaling: C4 = 8M in all, C5 = 1M in all).  Rank r owns the
+    contiguous shard `shard_range(total, r, world)` (shards may differ by one query)."""
     total_or_batch, mode, config_truth, config_k, text = CONFIGS[name]
-    per_gpu = total_or_batch if mode == "per_gpu" else total_or_batch // world
+    total = total_or_batch * world if mode == "per_gpu" else total_or_batch
     scaling = "weak" if mode == "per_gpu" else "strong"
     custom = queries is not None or truth is not None or k is not None
-    if queries is not None:
-        per_gpu, scaling = queries, "weak"
-    return (per_gpu, truth if truth is not None else config_truth, k if k is not None else config_k, scaling, text,
+    if queries is not None and mode == "per_gpu":
+        total = queries * world            # --queries = per-GPU batch of a weak-scaling configuration
+    elif queries is not None:
+        total = queries                    # --queries = the job's total of a strong-scaling configuration
+    return (total, truth if truth is not None else config_truth, k if k is not None else config_k, scaling, text,
             custom)
 
 
@@ -147,10 +164,14 @@ def spawn_ranks(gpus):
     """`--gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE this process touches the GPU and
     exit with their worst status.  Rank 0 inherits stdout (the JSON line); the other ranks' stdout goes to stderr."""
     import socket
+    from doppel_speller_amd import _lib, synth
+    _lib.build_library()          # hipcc only, no GPU call: the ranks must not race to rebuild a stale library
+    synth.build_native()
     with socket.socket() as probe:
         probe.bind(("127.0.0.1", 0))
         port = probe.getsockname()[1]
     ranks = []
+    os.environ.setdefault("DS_HOST_THREADS", str(max(2, min(32, len(os.sched_getaffinity(0)) // gpus))))
     for rank in range(gpus):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -173,6 +194,9 @@ def main():
     parser.add_argument("--check", type=int, default=64, help="queries verified against the oracle after the run")
     parser.add_argument("--host-communicator", action="store_true",
                         help="gather through the TCP rendezvous instead of RCCL (rehearsals without N GPUs)")
+    parser.add_argument("--allow-host-fallback", action="store_true",
+                        help="if RCCL cannot be initialised, gather through the host instead of failing (rehearsals)")
+    parser.add_argument("--shared-dir", default=None, help="where rank 0 publishes the workload (default /dev/shm)")
     args = parser.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -184,15 +208,19 @@ def main():
         log(f"error: --gpus {args.gpus} but WORLD_SIZE={world}")
         sys.exit(2)
 
-    per_gpu, truth, k, scaling, text, custom = resolve_config(args.config, world, args.queries, args.truth, args.k)
+    total_queries, truth, k, scaling, text, custom = resolve_config(args.config, world, args.queries, args.truth, args.k)
     # DS_BENCH_FORCE_DIST=1 exercises the rendezvous / RCCL plumbing with a single rank (1-GPU rehearsal)
     distributed = world > 1 or os.environ.get("DS_BENCH_FORCE_DIST") == "1"
 
     import doppel_speller_amd as ds
     from doppel_speller_amd import _lib, synth
-    from doppel_speller_amd.distributed import HostCommunicator, RcclCommunicator, Rendezvous, RowGather
+    from doppel_speller_amd.distributed import (HostCommunicator, RcclCommunicator, Rendezvous, RowGather,
+                                                private_directory, shard_range)
 
-    device = 0 if os.environ.get("DS_BENCH_SAME_DEVICE") == "1" else local_rank   # rehearsals on a one-GPU box
+    same_device = os.environ.get("DS_BENCH_SAME_DEVICE") == "1"     # rehearsals: every rank on a one-GPU box's GPU
+    device = 0 if same_device else local_rank
+    q_begin, q_end = shard_range(total_queries, rank, world)
+    per_gpu = q_end - q_begin
     rendezvous = communicator = gather = None
     if distributed:
         rendezvous = Rendezvous.from_environment()
@@ -200,31 +228,63 @@ def main():
         if args.host_communicator:
             communicator = HostCommunicator(rendezvous)
         else:
-            # The path itself has no collective (queries are sharded, the truth index is replicated): the gather only
-            # assembles the result table.  If RCCL cannot be initialised the ranks AGREE (one flag each through the
-            # rendezvous) to gather through the host instead, and the line says so (`rccl_ranks` 0 + `communicator_note`).
+            # A job asked to run on N GPUs does not quietly measure a TCP gather: when RCCL cannot be initialised on any
+            # rank, every rank learns it (one flag each through the rendezvous), prints the reason and exits non-zero --
+            # unless a rehearsal switch allows the host gather, which the line then reports (`rccl_ranks` 0 + note).
             try:
                 communicator, failure = RcclCommunicator(rendezvous, device), b""
-            except Exception as error:  # noqa: BLE001 - reported on the line, never hidden
-                communicator, failure = None, f"rank {rank}: {error}".encode()[:400]
-            failures = [f.decode() for f in rendezvous.all_gather_bytes(failure) if f]
+            except Exception as error:  # noqa: BLE001 - reported by every rank, fatal unless a rehearsal switch is set
+                communicator, failure = None, f"rank {rank}: {type(error).__name__}: {error}".encode()[:400]
+            failures = [f.decode("utf-8", "replace") for f in rendezvous.all_gather_bytes(failure) if f]
             if failures:
                 if communicator is not None:
                     communicator.close()
+                if not (args.allow_host_fallback or same_device):
+                    log(f"rank {rank}: RCCL could not be initialised ({'; '.join(failures)}); no line is printed.  "
+                        "Rehearsals without N GPUs: --host-communicator or --allow-host-fallback")
+                    rendezvous.close()
+                    sys.exit(3)
                 communicator = HostCommunicator(rendezvous)
                 communicator_note = "RCCL initialisation failed, rows gathered through the host: " + "; ".join(failures)
-                log("warning: " + communicator_note)
+                if rank == 0:
+                    log("warning: " + communicator_note)
 
-    # ---- synthetic workload: truth replicated (same seed), queries distinct per rank
+    # ---- synthetic workload.  One rank: generated in place.  Several ranks: rank 0 generates ALL of it (truth side and
+    # the queries of every rank: one vocabulary, as one MatchMaker over all the data has), publishes it as .npy files in
+    # shared memory, and every rank maps it and takes its shard -- not N times the minutes and the gigabytes.
     t0 = time.perf_counter()
-    stop = heartbeat("generating the workload") if rank == 0 else (lambda: None)
-    workload = synth.make_workload(truth, per_gpu, seed=args.seed, query_seed=args.seed + 1000 * (rank + 1))
-    stop()
+    shared = None
+    if world == 1:
+        stop = heartbeat("generating the workload")
+        workload = synth.make_workload(truth, total_queries, seed=args.seed)
+        stop()
+    else:
+        import shutil
+        base = args.shared_dir or ("/dev/shm" if os.path.isdir("/dev/shm") else private_directory())
+        shared = os.path.join(base, f"ds_bench_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}")
+        if rank == 0:
+            stop = heartbeat("generating the workload")
+            shutil.rmtree(shared, ignore_errors=True)
+            failure = b""
+            try:
+                synth.publish_workload(synth.make_workload(truth, total_queries, seed=args.seed), shared)
+            except Exception as error:  # noqa: BLE001 - every rank must learn about it
+                failure = f"{type(error).__name__}: {error}".encode()[:400]
+            stop()
+            import atexit
+            atexit.register(shutil.rmtree, shared, True)
+        else:
+            failure = b""
+        failure = rendezvous.broadcast_bytes(failure if rank == 0 else None)
+        if failure:
+            log(f"rank {rank}: rank 0 could not generate the workload: {failure.decode()}")
+            sys.exit(4)
+        workload = synth.load_workload(shared)
     if rank == 0:
         log(f"workload: {time.perf_counter() - t0:.1f}s  {synth.workload_statistics(workload)}")
     t0 = time.perf_counter()
     stop = heartbeat("index build + upload") if rank == 0 else (lambda: None)
-    pipeline = ds.CandidatePipeline(workload, k, device=device)
+    pipeline = ds.CandidatePipeline(workload, k, device=device, q_begin=q_begin, q_end=q_end)
     stop()
     if rank == 0:
         log(f"upload + index build: {time.perf_counter() - t0:.1f}s  {pipeline.index.info()}")
@@ -235,7 +295,7 @@ def main():
         stream_handle = ctypes.c_void_p()
         _lib.check(_lib.lib().ds_stream_create(device, ctypes.byref(stream_handle)), "ds_stream_create")
         stream = stream_handle.value
-        gather = RowGather(communicator, per_gpu * world, k, device)
+        gather = RowGather(communicator, total_queries, k, device)
 
     def barrier():
         _lib.check(_lib.lib().ds_stream_sync(stream_handle, device), "sync")
@@ -313,13 +373,13 @@ def main():
         from oracle import oracle
         n_check = min(args.check, per_gpu)
         rows = pipeline.rows()[:n_check]
-        last = int(workload.q_rowptr[n_check])
+        first, last = int(workload.q_rowptr[q_begin]), int(workload.q_rowptr[q_begin + n_check])
         expected = oracle.jaccard_topk(workload.rowptr, workload.truth_idx, workload.idf32, workload.sums32,
-                                       workload.q_rowptr[:n_check + 1], workload.q_cols[:last],
-                                       workload.q_maxint[:n_check], k)
+                                       np.asarray(workload.q_rowptr[q_begin:q_begin + n_check + 1]) - first,
+                                       workload.q_cols[first:last], workload.q_maxint[q_begin:q_begin + n_check], k)
         assert np.array_equal(rows, expected), "top-k rows differ from the oracle"
         features = pipeline.features(n_check * k)
-        pair_q = np.repeat(np.arange(n_check), k)
+        pair_q = q_begin + np.repeat(np.arange(n_check), k)
         pair_t = rows.reshape(-1)
         reference = oracle.construct_features(workload.q_len[pair_q], workload.t_len[pair_t], workload.q_enc[pair_q],
                                               workload.t_enc[pair_t], workload.t_counts[pair_t], 1, workload.n_truth)
@@ -330,31 +390,55 @@ def main():
                                                             workload.q_enc[pair_q], workload.t_enc[pair_t], 1)))
 
     if rank == 0:
-        pairs_per_step = per_gpu * k * world
+        pairs_per_step = total_queries * k
         ms_per_step = 1000.0 * elapsed / args.steps
-        reference_bytes = synth.algorithmic_bytes_jaccard(workload, k)
+        reference_bytes = synth.algorithmic_bytes_jaccard(workload, k, q_begin, q_end)   # this rank's shard, like the kernel time
+        shard_columns = int(workload.q_rowptr[q_end]) - int(workload.q_rowptr[q_begin])
         mean_j = float(np.mean(jaccard_ms))
+        mean_f = float(np.mean(feature_ms))
         mean_topk = float(np.mean(topk_kernel_ms))   # ds_jaccard_topk_kernel alone (the dominant kernel)
         requested = int(stats["requested_bytes"])     # bytes the kernel asked global memory for, last launch
         achieved = requested / (mean_topk * 1e-3) / 1e9
+        build_id = _lib.lib().ds_build_id().decode()
         roofline = {"bound": "hbm", "kernel": "ds_jaccard_topk_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "algorithmic_bytes_per_launch": requested, "avg_launch_ms": mean_topk,
+                    "requested_bytes_per_launch": requested, "survey_8d_bytes_per_launch": reference_bytes,
+                    "frac_on_survey_8d_bytes": reference_bytes / (mean_topk * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "avg_launch_ms": mean_topk, "geometry": "narrow" if pipeline.index.info()["tile_rows"] == 12288 else "wide",
                     "bytes_per_query": requested / max(1, per_gpu),
-                    "note": "algorithmic bytes = what THIS kernel requests from global memory per launch (2-byte "
-                            "postings of the traversed lists + per-posting row info, sums32 of the dense scans, list "
-                            "pointers, per-column setup, refinement gathers, exact-stage probes), counted by a second "
-                            "instantiation of the kernel in one extra untimed launch; `traffic` = 2 * FETCH_SIZE + WRITE_SIZE of profiles/pmc_latest.json "
-                            "(FETCH_SIZE counts half of coalesced streams on gfx950) when measured on this build"}
+                    "note": "`achieved` / `frac` use requested_bytes_per_launch = what THIS kernel requests from global "
+                            "memory per launch (2-byte postings of the traversed lists + per-posting row info, sums32 of "
+                            "the dense scans, list pointers, per-column setup, refinement gathers, exact-stage probes), "
+                            "counted by a second instantiation of the kernel in one extra untimed launch.  "
+                            "survey_8d_bytes_per_launch = SURVEY.md 8d's B_jac, what the REFERENCE's algorithm reads: the "
+                            "kernel skips most of it (MaxScore), so frac_on_survey_8d_bytes exceeds 1 -- a speed-up over "
+                            "the reference algorithm's bandwidth floor, not an efficiency.  `traffic` = 2 * FETCH_SIZE + "
+                            "WRITE_SIZE per launch from the entry of profiles/pmc_latest.json measured on this build "
+                            "and workload (FETCH_SIZE counts half of coalesced streams on gfx950), else null"}
         pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as handle:
                 pmc = json.load(handle)
-            same = (pmc.get("queries") == per_gpu and pmc.get("truth") == truth and pmc.get("k") == k and
-                    pmc.get("build_id") == _lib.lib().ds_build_id().decode())
-            if same:  # counters of THIS build on THIS workload (scripts/profile_pmc.sh); stale files are ignored
-                roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
-                roofline["bound_model"] = pmc.get("bound_model")
+            for entry in pmc.get("entries", [pmc]):   # one entry per (workload, build id): scripts/profile_pmc.sh
+                if (entry.get("queries") == per_gpu and entry.get("truth") == truth and entry.get("k") == k and
+                        entry.get("build_id") == build_id):   # stale entries are ignored
+                    roofline["traffic"] = entry.get("hbm_bytes_per_launch")
+                    roofline["bound_model"] = entry.get("bound_model")
+        # ds_construct_features_kernel: bound by VALU integer work, not HBM.  Ceiling of the REFERENCE's DP
+        # formulation: 256 CUs x 128 lanes per clock (the f32 vector peak of the microarchitecture guide, 157.3 TF = 2 x
+        # 256 x 128 x 2.4 GHz) / 5 integer operations per DP cell.  The kernel computes LCS bit-parallel (64 cells per 64-bit
+        # step), so this is reference-cells per second against the cost of computing them literally.
+        valu_cells_peak = 256 * 128 * 2.4e9 / 5.0
+        cells_rate = None if cells_per_pair is None else cells_per_pair * per_gpu * k / (mean_f * 1e-3)
+        feature_bytes = per_gpu * k * 330                       # indexed form: 8 B of indexes + 264 B out + ~58 B of titles
+        roofline_features = {
+            "bound": "valu-int", "kernel": "ds_construct_features_kernel", "achieved": cells_rate,
+            "peak": valu_cells_peak, "unit": "reference DP cells/s",
+            "frac": None if cells_rate is None else cells_rate / valu_cells_peak,
+            "hbm_frac": feature_bytes / (mean_f * 1e-3) / 1e9 / HBM_PEAK_GBS, "hbm_bytes_per_pair": 330,
+            "avg_launch_ms": mean_f, "reference_dp_cells_per_pair": cells_per_pair,
+            "note": "peak = 256 CUs x 128 integer lanes x 2.4 GHz / 5 operations per DP cell (SURVEY.md 8d); cells counted "
+                    "by the oracle's feature_cells on the verified pairs"}
         line = {
             "metric": "candidate-pairs scored/sec (Jaccard top-k + Levenshtein), 100k x 500k titles",
             "value": pairs_per_step / (elapsed / args.steps),
@@ -365,23 +449,22 @@ def main():
             "data": "synthetic",
             "config": {"workload": (f"{args.config}: " if not custom else "custom: ") +
                                    (f"{world}xMI355X: " + (text if not custom else "") +
-                                    f" [{per_gpu} queries per GPU x {truth} truth titles (replicated), tri-gram vocab "
+                                    f" [{total_queries} queries in all, {per_gpu} per GPU x {truth} truth titles (replicated), tri-gram vocab "
                                     f"{workload.n_columns}, top-{k}" +
                                     (", one RCCL all-gather of the rows per step]" if world > 1 else "]")),
                        "name": args.config if not custom else "custom",
-                       "queries_per_gpu": per_gpu, "truth_titles": truth, "k": k,
+                       "queries_per_gpu": per_gpu, "queries": total_queries, "truth_titles": truth, "k": k,
                        "seed": args.seed, "parallelism": f"query-shard x{world}"},
-            "stages_ms": {"jaccard_topk": mean_j, "construct_features": float(np.mean(feature_ms)),
+            "stages_ms": {"jaccard_topk": mean_j, "construct_features": mean_f,
                           "ds_jaccard_topk_kernel": mean_topk,
                           "ds_jaccard_dense_kernel": float(np.mean(dense_kernel_ms))},
-            "queries_per_s": per_gpu * world / (elapsed / args.steps),
+            "queries_per_s": total_queries / (elapsed / args.steps),
             "per_stage": {
                 "jaccard_queries_per_s": per_gpu / (mean_j * 1e-3),
-                "jaccard_postings_per_s": (reference_bytes - per_gpu * (4 * truth + 4 * k)
-                                           - 16 * int(workload.q_rowptr[-1])) / 4 / (mean_j * 1e-3),
-                "feature_pairs_per_s": per_gpu * k / (float(np.mean(feature_ms)) * 1e-3),
-                "feature_reference_dp_cells_per_s": None if cells_per_pair is None else
-                    cells_per_pair * per_gpu * k / (float(np.mean(feature_ms)) * 1e-3),
+                "jaccard_postings_per_s": (reference_bytes - per_gpu * (4 * truth + 4 * k) - 16 * shard_columns) / 4 /
+                                          (mean_j * 1e-3),
+                "feature_pairs_per_s": per_gpu * k / (mean_f * 1e-3),
+                "feature_reference_dp_cells_per_s": cells_rate,
                 "reference_dp_cells_per_pair": cells_per_pair},
             "dense_path_queries": int(stats["dense_queries"]), "exact_candidates_per_query":
                 stats["exact_candidates"] / max(1, per_gpu),
@@ -390,12 +473,12 @@ def main():
             "tiles": {"sparse": stats["sparse_tiles"], "dense": stats["dense_tiles"]},
             "skipped_columns_per_query": stats["skipped_columns"] / max(1, per_gpu),
             "roofline": roofline,
-            # SURVEY.md 8d's figure: what the REFERENCE's algorithm reads (4-byte postings of every query column, 4 N
-            # bytes of sums per query ...).  The kernel skips most of it, hence a quotient above the HBM peak: this is
-            # a speed-up over the reference algorithm's bandwidth floor, not an efficiency.
-            "reference_algorithmic_bytes_per_launch": reference_bytes,
-            "speedup_over_reference_hbm_floor": reference_bytes / (mean_topk * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "build_id": _lib.lib().ds_build_id().decode(),
+            "roofline_features": roofline_features,
+            "speedup_over_reference_hbm_floor": roofline["frac_on_survey_8d_bytes"],
+            "gpu_seconds_in_timed_region": elapsed,
+            "host_setup_note": "workload generation, index build and the CPU baseline run on the host before / after the "
+                               "timed region; the GPU is busy for `gpu_seconds_in_timed_region` of the process's life",
+            "build_id": build_id,
         }
         if distributed:
             line["rccl_ranks"] = world if communicator.on_device else 0
@@ -416,6 +499,9 @@ def main():
         rendezvous.barrier()
         communicator.close()
         rendezvous.close()
+    if shared is not None and rank == 0:
+        import shutil
+        shutil.rmtree(shared, ignore_errors=True)
 
 
 if __name__ == "__main__":

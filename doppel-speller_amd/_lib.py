@@ -56,6 +56,19 @@ def build_library(force=False, verbose=False):
     wanted = source_id()
     if not force and binary_id(target) == wanted:
         return target
+    # One builder at a time (the ranks of a multi-GPU job may all find the same stale library at once): the others wait
+    # for the lock, find the finished binary and return.  The link step writes a scratch file that replaces the target
+    # atomically, so a process that is loading the old library never sees a half-written one.
+    import fcntl
+    with open(target + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and binary_id(target) == wanted:   # somebody else built it while this process waited
+            return target
+        _compile_and_link(sources, target, wanted, verbose)
+    return target
+
+
+def _compile_and_link(sources, target, wanted, verbose):
     # one hipcc per translation unit, side by side (the two geometries of the Jaccard kernels take a minute each), then
     # one link step
     import concurrent.futures
@@ -73,11 +86,12 @@ def build_library(force=False, verbose=False):
             subprocess.check_call(command)
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(4, len(sources))) as pool:
             list(pool.map(compile_one, zip(sources, objects)))
-        link = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objects
+        linked = f"{target}.{os.getpid()}.tmp"
+        link = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", linked] + objects
         if verbose:
             print(" ".join(link), flush=True)
         subprocess.check_call(link)
-    return target
+        os.replace(linked, target)
 
 
 def _declare(handle):
@@ -177,7 +191,7 @@ def lib():
             if os.environ.get("DS_AUTO_REBUILD", "1") != "0" and shutil.which("hipcc") and "DS_LIBRARY" not in os.environ:
                 print(f"doppel-speller_amd: {path} was built from other sources ({binary_id(path)} != {sources}); "
                       "rebuilding", file=sys.stderr, flush=True)
-                build_library(force=True)
+                build_library()
             else:
                 raise DoppelError(
                     f"{path} was built from sources {binary_id(path)}, but csrc/ + include/ are now {sources}: rebuild "

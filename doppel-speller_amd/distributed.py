@@ -59,13 +59,40 @@ def _receive(sock):
     return exactly(length)
 
 
+def private_directory():
+    """<tmp>/ds_<uid>: created 0700 and verified to be a real directory of this user (never a planted link)."""
+    import stat
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"ds_{os.getuid()}")
+    try:
+        os.mkdir(path, 0o700)
+    except FileExistsError:
+        pass
+    info = os.lstat(path)
+    if not stat.S_ISDIR(info.st_mode) or info.st_uid != os.getuid():
+        raise _lib.DoppelError(f"{path} is not a directory owned by this user")
+    return path
+
+
+def _write_private(path, text):
+    """Create `path` exclusively (no link is followed, nothing is overwritten in place) and publish it atomically."""
+    scratch = f"{path}.{os.getpid()}.tmp"
+    if os.path.lexists(scratch):
+        os.unlink(scratch)
+    descriptor = os.open(scratch, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    with os.fdopen(descriptor, "w") as handle:
+        handle.write(text)
+    os.replace(scratch, path)
+
+
 class Rendezvous:
     """World-wide host-side exchange for one process per GPU: rank 0 listens on (address, port), every other rank
     connects.  All operations are collective and must be called by every rank in the same order."""
 
     _MAGIC = b"DSRV1"
 
-    def __init__(self, rank, world_size, address="127.0.0.1", port=29533, timeout=600.0, port_file=None):
+    def __init__(self, rank, world_size, address="127.0.0.1", port=29533, timeout=600.0, port_file=None,
+                 hello_timeout=5.0):
         """port: where rank 0 listens.  With `port_file`, rank 0 falls back to any free port when `port` is taken and
         publishes the port it got in that file (written atomically); the other ranks read it before every attempt."""
         self.rank, self.world_size = rank, world_size
@@ -74,7 +101,7 @@ class Rendezvous:
         if world_size == 1:
             return
         if rank == 0:
-            if port_file and os.path.exists(port_file):
+            if port_file and os.path.lexists(port_file):
                 os.unlink(port_file)  # a previous job's
             self.server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             self.server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -85,17 +112,16 @@ class Rendezvous:
                     raise
                 self.server.bind((address, 0))
             if port_file:
-                with open(port_file + ".tmp", "w") as handle:
-                    handle.write(str(self.server.getsockname()[1]))
-                os.replace(port_file + ".tmp", port_file)
+                _write_private(port_file, str(self.server.getsockname()[1]))
             self.server.listen(world_size)
             self.server.settimeout(timeout)
             while len(self.peers) < world_size - 1:
                 connection, _ = self.server.accept()
                 connection.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                connection.settimeout(timeout)
+                connection.settimeout(hello_timeout)  # a stray connection that says nothing costs seconds, not `timeout`
                 try:
                     hello = _receive(connection)
+                    connection.settimeout(timeout)
                 except (ConnectionError, OSError, struct.error):
                     connection.close()
                     continue
@@ -134,9 +160,8 @@ class Rendezvous:
         """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as `torch.distributed.run` (or bench.py's own launcher) export
         them.  The launcher's store owns MASTER_PORT itself, so the star listens `port_offset` above it -- or, when
         that port is taken, wherever rank 0 finds room: the port is published in a file named after MASTER_PORT."""
-        import tempfile
         master_port = int(os.environ.get("MASTER_PORT", "29533"))
-        port_file = os.path.join(tempfile.gettempdir(), f"ds_rendezvous_{os.getuid()}_{master_port}.port")
+        port_file = os.path.join(private_directory(), f"rendezvous_{master_port}.port")
         return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
                    os.environ.get("MASTER_ADDR", "127.0.0.1"), master_port + port_offset, port_file=port_file)
 
@@ -204,10 +229,9 @@ _NCCL_TYPES = {np.dtype(np.int8): 0, np.dtype(np.uint8): 1, np.dtype(np.int32): 
 
 
 def _load_rccl():
-    for name in (os.environ.get("DS_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
-                 "/opt/rocm/lib/librccl.so"):
-        if not name:
-            continue
+    override = os.environ.get("DS_RCCL_LIBRARY")   # when set, ONLY this file is tried
+    for name in ((override,) if override else ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
+                                               "/opt/rocm/lib/librccl.so")):
         try:
             handle = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
         except OSError:
@@ -220,7 +244,8 @@ def _load_rccl():
                                          ctypes.c_void_p, ctypes.c_void_p]
         handle.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         return handle
-    raise _lib.DoppelError("librccl.so not found (set DS_RCCL_LIBRARY)")
+    raise _lib.DoppelError(f"{override}: cannot be loaded (DS_RCCL_LIBRARY)" if override else
+                           "librccl.so not found (set DS_RCCL_LIBRARY)")
 
 
 class _StdoutToStderr:
@@ -247,28 +272,35 @@ class RcclCommunicator:
     on the caller's HIP stream (device pointers in, device pointers out, no host staging)."""
     on_device = True
 
-    def __init__(self, rendezvous, device):
+    def __init__(self, rendezvous, device, select_device=True):
+        """Collective over the rendezvous.  Every rank takes part in TWO host exchanges before ncclCommInitRank -- the
+        id broadcast and one readiness flag per rank -- whatever happened to it locally: a rank that failed (no
+        librccl, a LOCAL_RANK beyond the visible devices ...) reports its error text, and every rank raises.  Nobody
+        enters the collective ncclCommInitRank(world_size) with a rank missing (it would block forever)."""
         self.rendezvous = rendezvous
         self.rank, self.world_size, self.device = rendezvous.rank, rendezvous.world_size, device
         unique, failure = _NcclUniqueId(), None
         try:
             self.rccl = _load_rccl()
-            _lib.check(_lib.lib().ds_stream_sync(None, device), "select device")  # hipSetDevice(device) for RCCL
+            if select_device:
+                _lib.check(_lib.lib().ds_stream_sync(None, device), "select device")  # hipSetDevice(device) for RCCL
             if self.rank == 0:
                 with _StdoutToStderr():
                     status = self.rccl.ncclGetUniqueId(ctypes.byref(unique))
                 self._check(status, "ncclGetUniqueId")
-        except Exception as error:  # noqa: BLE001 - re-raised below, after the broadcast every rank takes part in
+        except Exception as error:  # noqa: BLE001 - reported to every rank below
             failure = error
-        # every rank reaches the broadcast whatever happened before it: rank 0 sends an empty id when it failed, so the
-        # other ranks raise instead of waiting for an id that never comes
         raw = rendezvous.broadcast_bytes(
             (b"" if failure else ctypes.string_at(ctypes.byref(unique), 128)) if self.rank == 0 else None)
+        if failure is None and len(raw) != 128:
+            failure = _lib.DoppelError("rank 0 could not create an RCCL unique id" if not raw
+                                       else "rendezvous delivered a malformed RCCL unique id")
+        flags = rendezvous.all_gather_bytes(b"" if failure is None else f"rank {self.rank}: {failure}".encode()[:400])
         if failure is not None:
             raise failure
-        if len(raw) != 128:
-            raise _lib.DoppelError("rank 0 could not create an RCCL unique id" if not raw
-                                   else "rendezvous delivered a malformed RCCL unique id")
+        others = [flag.decode("utf-8", "replace") for flag in flags if flag]
+        if others:
+            raise _lib.DoppelError("RCCL communicator not created, another rank failed: " + "; ".join(others))
         ctypes.memmove(ctypes.byref(unique), raw, 128)
         self.comm = ctypes.c_void_p()
         with _StdoutToStderr():

@@ -299,6 +299,33 @@ def make_workload(n_truth, n_queries, seed=DEFAULT_SEED, vocabulary_size=None, q
         t_flat=t_flat, t_off=t_off, q_flat=q_flat, q_off=q_off, problem=problem)
 
 
+_PUBLISHED = ("rowptr", "truth_idx", "idf32", "idf64", "sums32", "q_rowptr", "q_cols", "q_maxint", "t_enc", "t_len",
+              "t_counts", "q_enc", "q_len", "title_id", "actual_row", "t_flat", "t_off", "q_flat", "q_off")
+
+
+def publish_workload(w, directory):
+    """Write a workload as .npy files (+ meta.json, last) into `directory` -- /dev/shm for the ranks of one node: rank 0
+    generates the workload once, the other ranks map it (`load_workload`) instead of repeating minutes of host work and
+    holding eight private copies of a 12.75 GB title table."""
+    import json
+    os.makedirs(directory, exist_ok=True)
+    for name in _PUBLISHED:
+        np.save(os.path.join(directory, name + ".npy"), np.asarray(getattr(w, name)))
+    with open(os.path.join(directory, "meta.json.tmp"), "w") as handle:
+        json.dump({"n_truth": int(w.n_truth), "n_queries": int(w.n_queries), "n_columns": int(w.n_columns),
+                   "seed": int(w.seed)}, handle)
+    os.replace(os.path.join(directory, "meta.json.tmp"), os.path.join(directory, "meta.json"))
+
+
+def load_workload(directory):
+    """The workload of `publish_workload`, arrays memory-mapped read-only (shared page cache between the ranks)."""
+    import json
+    with open(os.path.join(directory, "meta.json")) as handle:
+        meta = json.load(handle)
+    arrays = {name: np.load(os.path.join(directory, name + ".npy"), mmap_mode="r") for name in _PUBLISHED}
+    return SimpleNamespace(**meta, **arrays)
+
+
 def workload_statistics(w, positive_sample=0):
     """The acceptance numbers of SURVEY.md section 8d for a workload.  `positive_sample` > 0 also measures the share
     of truth titles with a positive score (at least one shared tri-gram) on that many evenly spaced queries."""
@@ -325,11 +352,14 @@ def workload_statistics(w, positive_sample=0):
     return stats
 
 
-def algorithmic_bytes_jaccard(w, k):
-    """B_jac summed over the queries: 4*sum|P_g| + 4*N + 16*|G_q| + 4*k per query."""
+def algorithmic_bytes_jaccard(w, k, q_begin=0, q_end=None):
+    """B_jac summed over the queries [q_begin, q_end): 4*sum|P_g| + 4*N + 16*|G_q| + 4*k per query (SURVEY.md section
+    8d) -- what the REFERENCE's algorithm reads."""
+    q_end = w.n_queries if q_end is None else q_end
+    first, last = int(w.q_rowptr[q_begin]), int(w.q_rowptr[q_end])
     posting_lengths = np.diff(w.rowptr)
-    touched = int(posting_lengths[w.q_cols].sum())
-    return 4 * touched + w.n_queries * (4 * w.n_truth + 4 * k) + 16 * int(w.q_rowptr[-1])
+    touched = int(posting_lengths[w.q_cols[first:last]].sum())
+    return 4 * touched + (q_end - q_begin) * (4 * w.n_truth + 4 * k) + 16 * (last - first)
 
 
 def make_forest(seed=DEFAULT_SEED, n_trees=300, depth=6, n_features=66):

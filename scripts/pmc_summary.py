@@ -10,7 +10,10 @@ MI355X (profiles/r02_calibration.txt), 4 waves per SIMD as in the kernel:
 FETCH_SIZE (KiB) reports exactly half of the bytes of coalesced streams at 4, 8 and 16 bytes per lane (same file), so
 HBM traffic = 2 * FETCH_SIZE + WRITE_SIZE for this kernel, whose reads are coalesced posting / sums streams.
 
-usage: pmc_summary.py <tag> <queries> <truth> <k> [--write]
+usage: pmc_summary.py <tag> [--write]      (workload = the `config` of the bench line of the fetch pass)
+
+profiles/pmc_latest.json holds ONE ENTRY PER WORKLOAD ({"entries": [...]}, each with the build id it was measured on);
+--write replaces the entry of this workload and keeps the others.
 """
 import collections
 import csv
@@ -24,8 +27,12 @@ SIMDS, CUS, HBM_PEAK = 1024, 256, 8.0e12
 
 
 def main():
-    tag, queries, truth, k = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    tag = sys.argv[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "gpurun_out", f"pmc_{tag}_fetch.json")) as handle:
+        bench_line = json.loads(handle.read().strip().splitlines()[-1])
+    queries, truth, k = (bench_line["config"][name] for name in ("queries_per_gpu", "truth_titles", "k"))
+    print(f"workload: {bench_line['config']['workload']}")
     totals = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.Counter()
     durations = collections.defaultdict(list)
@@ -75,14 +82,23 @@ def main():
     if "--write" in sys.argv:
         sys.path.insert(0, root)
         from doppel_speller_amd import _lib
-        out = {"queries": queries, "truth": truth, "k": k, "kernel": "ds_jaccard_topk_kernel",
+        out = {"queries": queries, "truth": truth, "k": k, "kernel": kernel.split("<")[0],
+               "geometry": bench_line["roofline"].get("geometry"), "tag": tag,
+               "requested_bytes_per_launch": bench_line["roofline"].get("requested_bytes_per_launch"),
                "build_id": _lib.source_id(), "FETCH_SIZE_KiB_per_launch": c["FETCH_SIZE"],
                "WRITE_SIZE_KiB_per_launch": c["WRITE_SIZE"], "hbm_bytes_per_launch": hbm_bytes,
                "note": "hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes): FETCH_SIZE counts half the bytes of "
                        "coalesced 4/8/16-byte-per-lane streams on gfx950 (profiles/r02_calibration.txt)",
                "bound_model": model}
-        with open(os.path.join(root, "profiles", "pmc_latest.json"), "w") as handle:
-            json.dump(out, handle, indent=1)
+        path = os.path.join(root, "profiles", "pmc_latest.json")
+        entries = []
+        if os.path.exists(path):
+            with open(path) as handle:
+                previous = json.load(handle)
+            entries = [e for e in previous.get("entries", [previous])
+                       if (e.get("queries"), e.get("truth"), e.get("k")) != (queries, truth, k)]
+        with open(path, "w") as handle:
+            json.dump({"entries": entries + [out]}, handle, indent=1)
 
 
 if __name__ == "__main__":

@@ -159,3 +159,122 @@ def test_rccl_initialisation_failure_raises_on_every_rank_without_hanging(tmp_pa
     for rank in range(2):
         outcomes = open(f"{out}.{rank}").read().splitlines()
         assert len(outcomes) == 2 and all("Error" in outcome for outcome in outcomes), outcomes
+
+
+_STUB_RCCL = r"""
+// Test double of librccl.so for the CPU container: enough of the API for RcclCommunicator.__init__ to run.
+// ncclCommInitRank records that it was entered (a real one would block waiting for the missing rank).
+#include <stdio.h>
+#include <string.h>
+typedef struct { char internal[128]; } ncclUniqueId;
+const char *ncclGetErrorString(int status) { return status ? "stub error" : "ok"; }
+int ncclGetUniqueId(ncclUniqueId *id) { memset(id, 7, sizeof(*id)); return 0; }
+int ncclCommInitRank(void **comm, int world, ncclUniqueId id, int rank) {
+    FILE *mark = fopen(STUB_MARK, "a"); if (mark) { fprintf(mark, "entered %d\n", rank); fclose(mark); }
+    *comm = (void *)1; return 0; }
+int ncclAllGather(const void *s, void *r, size_t n, int t, void *c, void *st) { return 0; }
+int ncclCommDestroy(void *c) { return 0; }
+"""
+
+
+def _rccl_one_rank_fails_worker(rank, world, port, out_path, stub, missing):
+    sys.path.insert(0, ROOT)
+    os.environ["DS_RCCL_LIBRARY"] = missing if rank == 1 else stub     # only rank 1 cannot load its library
+    from doppel_speller_amd.distributed import RcclCommunicator, Rendezvous
+    rendezvous = Rendezvous(rank, world, port=port)
+    try:
+        RcclCommunicator(rendezvous, rank, select_device=False)        # no GPU in this container
+        outcome = "initialised"
+    except Exception as error:  # noqa: BLE001 - the message is the result
+        outcome = f"{type(error).__name__}: {error}"
+    flags = rendezvous.all_gather_bytes(outcome.encode())
+    with open(f"{out_path}.{rank}", "w") as handle:
+        handle.write("\n".join(flag.decode() for flag in flags))
+    rendezvous.close()
+
+
+def test_rccl_failure_of_a_single_non_zero_rank_raises_everywhere(tmp_path):
+    """rank 1 fails locally before ncclCommInitRank (its librccl cannot be loaded) while ranks 0 and 2
+    are fine.  Every rank must raise after the readiness exchange and NOBODY may enter the collective ncclCommInitRank
+    (it would wait for rank 1 forever).  librccl is a test double here: the container has no GPU."""
+    import subprocess
+    mark = str(tmp_path / "entered.txt")
+    source = tmp_path / "stub_rccl.c"
+    source.write_text(_STUB_RCCL)
+    stub = str(tmp_path / "libstub_rccl.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", f'-DSTUB_MARK="{mark}"', str(source), "-o", stub])
+    context = multiprocessing.get_context("spawn")
+    port = _free_port()
+    out = str(tmp_path / "outcome")
+    ranks = [context.Process(target=_rccl_one_rank_fails_worker, args=(r, 3, port, out, stub, str(tmp_path / "no.so")))
+             for r in range(3)]
+    for process in ranks:
+        process.start()
+    for process in ranks:
+        process.join(120)
+        assert process.exitcode == 0
+    for rank in range(3):
+        outcomes = open(f"{out}.{rank}").read().splitlines()
+        assert len(outcomes) == 3 and all("DoppelError" in outcome for outcome in outcomes), outcomes
+        assert "another rank failed" in outcomes[0] and "rank 1" in outcomes[0] and "DS_RCCL_LIBRARY" in outcomes[1]
+    assert not os.path.exists(mark)          # ncclCommInitRank was never entered
+
+    # the same three ranks with a loadable library everywhere do enter it (the test double works)
+    port = _free_port()
+    ranks = [context.Process(target=_rccl_one_rank_fails_worker, args=(r, 3, port, out, stub, stub)) for r in range(3)]
+    for process in ranks:
+        process.start()
+    for process in ranks:
+        process.join(120)
+        assert process.exitcode == 0
+    assert open(f"{out}.0").read().splitlines() == ["initialised"] * 3
+    assert sorted(open(mark).read().split()) == sorted("entered 0 entered 1 entered 2".split())
+
+
+def test_rendezvous_ignores_a_silent_stray_connection(tmp_path):
+    """A connection that sends nothing holds rank 0's accept loop for `hello_timeout`, not for the collective timeout."""
+    import threading
+    import time
+    from doppel_speller_amd.distributed import Rendezvous
+    port = _free_port()
+    results = {}
+
+    def rank0():
+        results[0] = Rendezvous(0, 2, port=port, timeout=120.0, hello_timeout=1.0)
+
+    server = threading.Thread(target=rank0)
+    server.start()
+    time.sleep(0.3)
+    stray = socket.create_connection(("127.0.0.1", port))      # says nothing
+    started = time.time()
+    peer = Rendezvous(1, 2, port=port, timeout=120.0)
+    server.join(30)
+    assert 0 in results and time.time() - started < 20
+    exchange = threading.Thread(target=lambda: results.__setitem__("a", results[0].all_gather_bytes(b"zero")))
+    exchange.start()
+    assert peer.all_gather_bytes(b"one") == [b"zero", b"one"]
+    exchange.join(10)
+    assert results["a"] == [b"zero", b"one"]
+    stray.close()
+    peer.close()
+    results[0].close()
+
+
+def test_published_workload_round_trip(tmp_path):
+    """bench.py with N > 1: rank 0 publishes the whole workload as .npy files, the other ranks map it read-only and take
+    their query shard -- every array identical, and the mapped form feeds the same host entry points."""
+    from doppel_speller_amd import synth
+    from doppel_speller_amd.distributed import shard_range, slice_queries
+    w = synth.make_workload(4000, 301, seed=21)
+    synth.publish_workload(w, str(tmp_path / "shared"))
+    mapped = synth.load_workload(str(tmp_path / "shared"))
+    assert (mapped.n_truth, mapped.n_queries, mapped.n_columns) == (4000, 301, w.n_columns)
+    for name in synth._PUBLISHED:
+        assert np.array_equal(np.asarray(getattr(mapped, name)), getattr(w, name)), name
+        assert not getattr(mapped, name).flags.writeable
+    begin, end = shard_range(301, 1, 2)
+    a, b = slice_queries(w.q_rowptr, w.q_cols, w.q_maxint, begin, end), \
+        slice_queries(mapped.q_rowptr, mapped.q_cols, mapped.q_maxint, begin, end)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert synth.algorithmic_bytes_jaccard(mapped, 10, begin, end) + synth.algorithmic_bytes_jaccard(mapped, 10, 0, begin) == \
+        synth.algorithmic_bytes_jaccard(w, 10)

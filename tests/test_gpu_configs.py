@@ -1,5 +1,7 @@
 """BASELINE.json's single-GPU configurations at their FULL size through the fused device-resident path:
-C2 = 100k queries x 500k truth titles, top-10; C3 = 1M queries x 5M truth titles, top-50.
+C2 = 100k queries x 500k truth titles, top-10; C3 = 1M queries x 5M truth titles, top-50 (= one GPU's shard of C4);
+and ONE GPU's shard of C5 (8 GPUs: 1M queries x 50M truth titles, top-100 + all features): 125,000 queries against
+the replicated 50M-row truth index.
 
 Every output row is checked through size-independent properties (index range, strictly descending row indexes,
 idempotence of a second launch, per-query status, feature identities that do not need the oracle), and the oracle is
@@ -10,11 +12,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _check_config(oracle, n_truth, n_queries, k, oracle_sample, seed=20260101):
+def _check_config(oracle, n_truth, n_queries, k, oracle_sample, seed=20260101, feature_sample=400):
+    import time
     import doppel_speller_amd as ds
     from doppel_speller_amd import synth
+    started = time.perf_counter()
     w = synth.make_workload(n_truth, n_queries, seed=seed)
+    generated = time.perf_counter()
     pipeline = ds.CandidatePipeline(w, k)
+    built = time.perf_counter()
+    print(f"[{n_queries} x {n_truth}, top-{k}] workload {generated - started:.1f} s, index build + uploads "
+          f"{built - generated:.1f} s", flush=True)
     pipeline.step()
     stats = pipeline.sync()
     rows = pipeline.rows()
@@ -35,7 +43,6 @@ def _check_config(oracle, n_truth, n_queries, k, oracle_sample, seed=20260101):
     assert found.mean() > 0.6
 
     # ---- every pair: feature identities that need no oracle (feature_engineering.py:164-169), in chunks of 4M pairs
-    words_of_truth = ((w.t_enc == 1).sum(axis=1) + 1).astype(np.int64)          # feature_engineering.py:105
     slots = np.arange(15)[None, :]
     chunk = 4_000_000 // k * k
     for first in range(0, n_queries * k, chunk):
@@ -44,7 +51,8 @@ def _check_config(oracle, n_truth, n_queries, k, oracle_sample, seed=20260101):
         pair_q = np.arange(first, first + features.shape[0], dtype=np.int64) // k
         assert np.array_equal(features[:, 0], w.q_len[pair_q].astype(np.float32))
         assert np.array_equal(features[:, 1], w.t_len[pair_t].astype(np.float32))
-        words_t = words_of_truth[pair_t]
+        distinct, where = np.unique(pair_t, return_inverse=True)                 # feature_engineering.py:105
+        words_t = ((w.t_enc[distinct] == 1).sum(axis=1) + 1).astype(np.int64)[where]
         assert np.array_equal(features[:, 3], words_t.astype(np.float32))
         assert (features[:, 4] >= 0).all() and (features[:, 4] <= 100).all()
         for block in (6, 21, 36, 51):                         # best ratios, word lengths, idf, ranks: NaN beyond the words
@@ -66,7 +74,7 @@ def _check_config(oracle, n_truth, n_queries, k, oracle_sample, seed=20260101):
     expected = oracle.jaccard_topk(w.rowptr, w.truth_idx, w.idf32, w.sums32, sub_rowptr, flat, w.q_maxint[sample], k)
     bad = np.nonzero((rows[sample] != expected).any(axis=1))[0]
     assert bad.shape[0] == 0, (sample[bad][:10], rows[sample][bad[:2]], expected[bad[:2]])
-    check = sample[:min(sample.shape[0], 400)]
+    check = sample[:min(sample.shape[0], feature_sample)]
     got = pipeline.features_of(check)
     pq = np.repeat(check, k)
     pt = rows[check].reshape(-1)
@@ -84,3 +92,16 @@ def test_c2_full_size(oracle):
 def test_c3_full_size(oracle):
     """BASELINE.json configs[2]: 1M queries x 5M truth titles, top-50 (175 score tiles, 50M pairs)."""
     _check_config(oracle, 5_000_000, 1_000_000, 50, oracle_sample=200)
+
+
+def test_c5_shard(oracle):
+    """BASELINE.json configs[4] as ONE of its 8 GPUs sees it: the truth index of 50M titles is replicated, the GPU owns
+    1M / 8 = 125,000 queries, top-100, and the full feature vector of its 12.5M pairs.  The host side (native title
+    generator, threaded ds_problem_create / ds_index_create, a7 encoders) must get there in about a minute."""
+    threads = oracle.num_threads()
+    oracle.set_num_threads(min(16, threads))    # one 600 MB N-vector pair per oracle thread at N = 50M
+    try:
+        stats = _check_config(oracle, 50_000_000, 125_000, 100, oracle_sample=30, feature_sample=50)
+    finally:
+        oracle.set_num_threads(threads)
+    assert stats["sparse_tiles"] > stats["dense_tiles"]

@@ -87,3 +87,89 @@ def test_bench_under_the_driver_launcher_falls_back_loudly_when_rccl_refuses():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["verified_queries"] == 32 and line["value"] > 0
     assert line["rccl_ranks"] == 0 and "ncclCommInitRank" in line["communicator_note"]
+
+
+def _driver_launcher(arguments, env):
+    import socket
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    for name in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(name, None)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                           "--gpus", "2"] + arguments, env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_bench_on_distinct_devices_exits_non_zero_when_rccl_cannot_start():
+    """`--gpus 2` on a box with ONE GPU and no rehearsal switch: rank 1's device does not exist, so the communicator cannot
+    be created.  Every rank learns it through the readiness exchange, nobody blocks in ncclCommInitRank, no JSON line is
+    printed and the job's exit status is non-zero -- a scaling run never silently measures a TCP gather."""
+    result = _driver_launcher(["--queries", "2000", "--truth", "60000", "--k", "10", "--steps", "1", "--warmup", "1",
+                               "--cpu-seconds", "0", "--check", "8"], dict(os.environ))
+    assert result.returncode != 0
+    assert not [line for line in result.stdout.splitlines() if line.startswith("{")], result.stdout[:2000]
+    assert "RCCL could not be initialised" in result.stderr
+
+
+def test_c5_rehearsal_two_ranks_share_one_published_workload():
+    """C5's flow with two rank processes on the box's one GPU: rank 0 generates the WHOLE workload once (5M truth titles
+    here, wide geometry, top-100 + features) and publishes it in shared memory, both ranks map it, build the replicated
+    index and take UNEVEN query shards (10000 / 10001); the rows are gathered through the host communicator."""
+    env = dict(os.environ, DS_BENCH_SAME_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    result = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C5", "--truth",
+                             "5000000", "--queries", "20001", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0",
+                             "--check", "16", "--host-communicator"], env=env, capture_output=True, text=True,
+                            timeout=1200)
+    assert result.returncode == 0, result.stderr[-3000:]
+    line = json.loads(result.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["queries"] == 20001
+    assert line["config"]["queries_per_gpu"] == 10000 and line["config"]["k"] == 100 and line["verified_queries"] == 16
+    assert line["roofline"]["geometry"] == "wide" and line["value"] > 0
+    assert not [name for name in os.listdir("/dev/shm") if name.startswith("ds_bench_")]     # rank 0 cleaned up
+
+
+def test_row_gather_pads_and_compacts_uneven_shards_on_the_device():
+    """RowGather's device path with shards that differ by one row (C4 / C5 on a GPU count that does not divide the
+    queries): the local rows are padded on the device, travel through ONE all_gather, and are compacted with
+    device-to-device copies.  The communicator is a test double of RcclCommunicator (one process, two ranks' buffers):
+    real RCCL needs two GPUs; everything else is the product path."""
+    import ctypes
+    from doppel_speller_amd import _lib
+    from doppel_speller_amd.distributed import RowGather, shard_sizes
+    n_queries, k = 2001, 7
+    sizes = shard_sizes(n_queries, 2)
+    rng = np.random.RandomState(3)
+    rows = rng.randint(0, 1 << 30, (n_queries, k)).astype(np.int32)
+    local = [_lib.DeviceArray.from_host(rows[:sizes[0]]), _lib.DeviceArray.from_host(rows[sizes[0]:])]
+    padded_other = {}
+
+    class TwoRanksInOneProcess:
+        on_device = True
+        world_size = 2
+
+        def __init__(self, rank):
+            self.rank = rank
+
+        def all_gather(self, send, stream=None, out=None):
+            row_bytes = send.shape[1] * 4
+            mine = ctypes.c_void_p(out.ptr.value + self.rank * send.shape[0] * row_bytes)
+            other = ctypes.c_void_p(out.ptr.value + (1 - self.rank) * send.shape[0] * row_bytes)
+            _lib.check(_lib.lib().ds_memcpy_d2d_async(mine, send.ptr, send.shape[0] * row_bytes, 0, None), "copy")
+            _lib.check(_lib.lib().ds_memcpy_d2d_async(other, padded_other[self.rank].ptr, send.shape[0] * row_bytes, 0,
+                                                      None), "copy")
+            return out
+
+    longest = max(sizes)
+    for rank in (0, 1):     # what the OTHER rank would send: its rows padded to the longest shard
+        padded = np.full((longest, k), -1, dtype=np.int32)
+        padded[:sizes[1 - rank]] = rows[:sizes[0]] if rank == 1 else rows[sizes[0]:]
+        padded_other[rank] = _lib.DeviceArray.from_host(padded)
+    for rank in (0, 1):
+        gather = RowGather(TwoRanksInOneProcess(rank), n_queries, k)
+        assert not gather.even and gather.local == sizes[rank]
+        for _ in range(2):      # buffers are reused
+            gathered = gather.gather(local[rank])
+        _lib.check(_lib.lib().ds_stream_sync(None, 0), "sync")
+        assert gathered.shape == (n_queries, k) and np.array_equal(gathered.to_host(), rows)

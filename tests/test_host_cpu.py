@@ -202,15 +202,21 @@ def test_bench_configurations_follow_baseline_json():
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
+    from doppel_speller_amd.distributed import shard_sizes
+    # resolve_config returns the queries of the WHOLE job; rank r owns shard_range(total, r, world)
     assert bench.resolve_config("C2", 1)[:4] == (100_000, 500_000, 10, "weak")
-    assert bench.resolve_config("C2", 8)[:4] == (100_000, 500_000, 10, "weak")       # fixed per-GPU batch
+    assert bench.resolve_config("C2", 8)[:4] == (800_000, 500_000, 10, "weak")       # fixed per-GPU batch
+    assert shard_sizes(800_000, 8) == [100_000] * 8
     assert bench.resolve_config("C3", 1)[:4] == (1_000_000, 5_000_000, 50, "weak")
-    assert bench.resolve_config("C4", 8)[:4] == (1_000_000, 5_000_000, 50, "strong")  # 8M queries in all
-    assert bench.resolve_config("C4", 2)[:4] == (4_000_000, 5_000_000, 50, "strong")
-    assert bench.resolve_config("C5", 8)[:4] == (125_000, 50_000_000, 100, "strong")  # 1M queries in all
+    assert bench.resolve_config("C4", 8)[:4] == (8_000_000, 5_000_000, 50, "strong")  # 8M queries in all
+    assert bench.resolve_config("C4", 2)[:4] == (8_000_000, 5_000_000, 50, "strong") and shard_sizes(8_000_000, 8) == [1_000_000] * 8
+    assert bench.resolve_config("C5", 8)[:4] == (1_000_000, 50_000_000, 100, "strong")  # 1M queries in all
+    assert shard_sizes(1_000_000, 8) == [125_000] * 8
     assert bench.resolve_config("C5", 1)[:4] == (1_000_000, 50_000_000, 100, "strong")
-    per_gpu, truth, k, scaling, _, custom = bench.resolve_config("C2", 4, queries=2000, truth=60000)
-    assert (per_gpu, truth, k, scaling, custom) == (2000, 60000, 10, "weak", True)
+    total, truth, k, scaling, _, custom = bench.resolve_config("C2", 4, queries=2000, truth=60000)
+    assert (total, truth, k, scaling, custom) == (8000, 60000, 10, "weak", True)     # --queries = per-GPU batch (weak)
+    total, truth, k, scaling, _, custom = bench.resolve_config("C5", 2, queries=4001, truth=60000)
+    assert (total, scaling) == (4001, "strong") and shard_sizes(total, 2) == [2000, 2001]   # --queries = job total (strong)
     import json
     with open(os.path.join(ROOT, "BASELINE.json")) as handle:
         configs = json.load(handle)["configs"]
