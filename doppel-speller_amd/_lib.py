@@ -48,11 +48,23 @@ def binary_id(path):
     return found.group(1).decode() if found else None
 
 
-def build_library(force=False, verbose=False):
+# Diagnostic builds of the same sources, next to the product library (selected with DS_LIBRARY=<path> by the tests that
+# use them): "boundscheck" checks every data-dependent global index of the fast Jaccard kernel (ds_jaccard_sync
+# stats[28..30]).
+VARIANTS = {"boundscheck": ["-DDS_BOUNDS_CHECK"]}
+
+
+def variant_path(variant):
+    return os.path.join(_HERE, f"libdoppel_amd_{variant}.so")
+
+
+def build_library(force=False, verbose=False, variant=None):
     """Compile csrc/*.hip for gfx950 into libdoppel_amd.so next to this file (hipcc cross-compiles without a GPU).
-    Rebuilds whenever the id baked into the existing binary differs from the sources' (not on mtimes)."""
+    Rebuilds whenever the id baked into the existing binary differs from the sources' (not on mtimes).
+    variant: one of VARIANTS -> libdoppel_amd_<variant>.so with the variant's extra flags."""
     sources = [os.path.join(_HERE, "csrc", name) for name in _SOURCES]
-    target = library_path()
+    target = library_path() if variant is None else variant_path(variant)
+    extra = [] if variant is None else VARIANTS[variant]
     wanted = source_id()
     if not force and binary_id(target) == wanted:
         return target
@@ -64,17 +76,17 @@ def build_library(force=False, verbose=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and binary_id(target) == wanted:   # somebody else built it while this process waited
             return target
-        _compile_and_link(sources, target, wanted, verbose)
+        _compile_and_link(sources, target, wanted, verbose, extra)
     return target
 
 
-def _compile_and_link(sources, target, wanted, verbose):
+def _compile_and_link(sources, target, wanted, verbose, extra=()):
     # one hipcc per translation unit, side by side (the two geometries of the Jaccard kernels take a minute each), then
     # one link step
     import concurrent.futures
     import tempfile
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f'-DDS_BUILD_ID="{wanted}"', "-I",
-             os.path.join(_ROOT, "include")] + os.environ.get("DS_BUILD_FLAGS", "").split()
+             os.path.join(_ROOT, "include")] + list(extra) + os.environ.get("DS_BUILD_FLAGS", "").split()
     with tempfile.TemporaryDirectory(prefix="ds_build_") as scratch:
         objects = [os.path.join(scratch, os.path.basename(source) + ".o") for source in sources]
 

@@ -106,7 +106,8 @@ class TruthIndex:
                                           list(stats)[16:22])),
                 "refines": stats[22], "raw_entries": stats[23], "refine_survivors": stats[24],
                 "raw_entries_sparse": stats[25], "topk_kernel_ms": stats[26] / 1000.0,
-                "dense_kernel_ms": stats[27] / 1000.0, "bounds_record": list(stats)[28:32]}
+                "dense_kernel_ms": stats[27] / 1000.0, "bounds_record": list(stats)[28:31],
+                "sparse_redos": stats[31]}
 
     def status(self, n_queries, stream=None):
         """int32[n_queries] of the last call: 0 fast kernel, 1 literal kernel, 2 fewer than k rows, 3 bad column."""

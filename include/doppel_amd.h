@@ -101,10 +101,13 @@ int ds_jaccard_topk_device(ds_index *index, const int64_t *d_q_rowptr, const int
  * candidate overflow in a sparse tile, in a dense tile, ties after pruning, fewer than k positive rows),
  * stats[22..25]=refine passes / raw entries / survivors / raw entries from sparse tiles (diagnostics),
  * stats[26]=duration of ds_jaccard_topk_kernel in microseconds (HIP events on the launch stream),
- * stats[27]=duration of ds_jaccard_dense_kernel in microseconds. */
+ * stats[27]=duration of ds_jaccard_dense_kernel in microseconds, stats[28..30]=first out-of-range index a
+ * -DDS_BOUNDS_CHECK build caught (site, index, limit; all 0 otherwise), stats[31]=epochs of sparse tiles that were
+ * processed again because the candidate buffer overflowed (the threshold is tightened first; results unaffected). */
 int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[32]);
 /* Per-query status of the last call (after synchronising `stream`): 0 = answered by the fast kernel, 1 = handed to and
- * answered by the literal kernel, 2 = fewer than k rows qualified (DS_E_TOP_N), 3 = bad column index (DS_E_ARG).
+ * answered by the literal kernel, 2 = fewer than k rows qualified (DS_E_TOP_N), 3 = bad column index (DS_E_ARG),
+ * 4 = the literal kernel could not hold the rows within 1e-6 of the k-th value (DS_E_INTERNAL; see ds_jaccard_topk).
  * stats[15] of ds_jaccard_sync = bytes requested by the fast kernel (only with ds_index_option "count_bytes"). */
 int ds_jaccard_status(ds_index *index, void *stream, int32_t *status, int64_t Q);
 
