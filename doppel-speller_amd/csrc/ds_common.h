@@ -134,6 +134,7 @@ struct ds_index {
     // duplicate rank of a row (word 5 of its record): rows with the same column set and sums32 bits but a larger index (saturating)
     bool literal_only = false;             // idf32 / sums32 hold negative or non-finite values: the bounds of the fast kernel
                                            // do not apply, every query takes the literal kernel
+    ds::DeviceBuffer<unsigned char> kernel_args;  // the fast kernel's argument block (read through the constant address space)
     ds::DeviceBuffer<int32_t> control;     // [16] work-queue head, slow-list length, error count, counters
     ds::DeviceBuffer<int32_t> status;      // per-query status of the last call (grown on demand)
     ds::DeviceBuffer<int32_t> slow_list;   // query ids routed to the exact dense kernel

@@ -11,7 +11,7 @@
 #define DS_NARROW_WGS_PER_CU 4
 #endif
 #ifndef DS_NARROW_CANDIDATES
-#define DS_NARROW_CANDIDATES 832
+#define DS_NARROW_CANDIDATES 768  // 832 before the item directory took 1.6 KiB of LDS
 #endif
 #ifndef DS_NARROW_PTR_TILES
 #define DS_NARROW_PTR_TILES 1

@@ -9,7 +9,7 @@
 #define DS_WIDE_WGS_PER_CU 2
 #endif
 #ifndef DS_WIDE_CANDIDATES
-#define DS_WIDE_CANDIDATES 1536  // 512 bytes go to the raw entries' tile bytes (epochs of 4 tiles)
+#define DS_WIDE_CANDIDATES 1472  // 512 bytes go to the raw entries' tile bytes (epochs of 4 tiles), 1.6 KiB to the item directory
 #endif
 #ifndef DS_WIDE_PTR_TILES
 #define DS_WIDE_PTR_TILES 3
