@@ -19,9 +19,6 @@
 #define DS_WGS_PER_CU DS_WIDE_WGS_PER_CU
 #define DS_CANDIDATES DS_WIDE_CANDIDATES
 #define DS_PTR_TILES DS_WIDE_PTR_TILES
-#ifndef DS_FAST_CONTROL_VOLATILE
-#define DS_FAST_CONTROL_VOLATILE 1  // measured: this geometry's fast kernel is 2.3 % slower with the relaxed-atomic control words
-#endif
 #ifndef DS_WIDE_EPOCH
 #define DS_WIDE_EPOCH 4  // measured at the C3 shape: 91.1 (1) / 88.9 (2) / 86.5 (4) / 85.9 ms (8); top-100: 58.4 (2) / 56.9 (4) / 56.8 (8)
 #endif
