@@ -145,6 +145,11 @@ struct ds_index {
     bool attributes_set = false;
     bool count_bytes = false;              // launch the instantiation of the fast kernel that counts its requested bytes
     int64_t last_queries = 0;
+    // last resort of the literal kernel (a query whose near-ties do not fit its LDS buffer): the argument block of the last
+    // launch, the geometry's resolver, and a float64[n_truth] scratch vector allocated on first need
+    std::vector<unsigned char> last_args;
+    int (*resolve_ties)(ds_index *, hipStream_t, const std::vector<int32_t> &) = nullptr;
+    ds::DeviceBuffer<double> row_scratch;
 };
 
 struct ds_titles {

@@ -107,7 +107,8 @@ int ds_jaccard_topk_device(ds_index *index, const int64_t *d_q_rowptr, const int
 int ds_jaccard_sync(ds_index *index, void *stream, int64_t stats[32]);
 /* Per-query status of the last call (after synchronising `stream`): 0 = answered by the fast kernel, 1 = handed to and
  * answered by the literal kernel, 2 = fewer than k rows qualified (DS_E_TOP_N), 3 = bad column index (DS_E_ARG),
- * 4 = the literal kernel could not hold the rows within 1e-6 of the k-th value (DS_E_INTERNAL; see ds_jaccard_topk).
+ * (4 is transient: a query whose near-ties did not fit the literal kernel's LDS buffer; ds_jaccard_sync answers it with a
+ * full-row scan through a float64[N] scratch vector in HBM, allocated on first need, and the status becomes 1.)
  * stats[15] of ds_jaccard_sync = bytes requested by the fast kernel (only with ds_index_option "count_bytes"). */
 int ds_jaccard_status(ds_index *index, void *stream, int32_t *status, int64_t Q);
 

@@ -161,3 +161,35 @@ def test_candidate_overflow_inside_an_epoch_is_redone_and_counted(oracle, tied):
         assert stats["dense_reasons"]["overflow_sparse"] == 1
     else:        # one redo under the tightened threshold is enough
         assert 1 <= stats["sparse_redos"] <= 3 and stats["dense_queries"] == 0
+
+
+def test_near_ties_beyond_the_literal_kernels_buffer_are_answered_by_the_row_scan(oracle):
+    """More rows within 1e-6 of the k-th value than the literal kernel's LDS buffer holds (3072), none of them twins and
+    none k-dominated: the values RISE towards lower row indexes in steps of 6e-14.  The fast kernel hands the query over
+    (ties), the streaming selection cannot compact it, and ds_jaccard_sync answers it with the reference's own method --
+    the whole float64 jaccard row in an HBM scratch vector (round 2 returned DS_E_INTERNAL here)."""
+    import doppel_speller_amd as ds
+    n_rows, k = 30000, 10
+    band = np.arange(10000, 14500)
+    columns = {0: band}
+    filler = np.setdiff1d(np.arange(n_rows), band)
+    for j, part in enumerate(np.array_split(filler, 50)):
+        columns[1 + j] = part
+    rowptr, truth_idx, idf32, idf64, _ = build_index(n_rows, columns)
+    sums32 = np.full(n_rows, 3.0, dtype=np.float32)
+    sums32[band] = (np.float32(2.0).view(np.uint32) + np.arange(band.shape[0], dtype=np.uint32)).view(np.float32)  # one ulp apart, >= the idf of column 0
+    q_rowptr = np.array([0, 1], dtype=np.int64)
+    q_cols = np.array([0], dtype=np.int32)
+    q_maxint = np.array([1000.0])
+    expected = oracle.jaccard_topk(rowptr, truth_idx, idf32, sums32, q_rowptr, q_cols, q_maxint, k)
+    assert np.array_equal(expected[0], np.arange(14499, 14489, -1))          # the k largest row indexes of the band
+    index = ds.TruthIndex(rowptr, truth_idx, idf32, sums32)
+    rows = index.top_k(q_rowptr, q_cols, q_maxint, k)
+    assert np.array_equal(rows, expected)
+    assert index.status(1)[0] == 1          # answered (literal path), not an error
+    # the same through the device entry points: the resolution happens inside ds_jaccard_sync
+    d_rowptr, d_cols, d_maxint = (ds._lib.DeviceArray.from_host(x) for x in (q_rowptr, q_cols, q_maxint))
+    d_rows = ds._lib.DeviceArray((1, k), np.int32)
+    index.top_k_device(d_rowptr.ptr, d_cols.ptr, d_maxint.ptr, 1, k, d_rows.ptr)
+    stats = index.sync()
+    assert stats["error_queries"] == 0 and stats["dense_queries"] == 1 and np.array_equal(d_rows.to_host(), expected)
