@@ -125,13 +125,15 @@ struct ds_index {
     ds::DeviceBuffer<uint16_t> postings;   // [n_quads * 4] (parity << 15) | (tile-local row >> 1); per (column, tile): even rows, padding, odd rows, padding
     ds::DeviceBuffer<uint16_t> posting_sums; // [n_quads * 4] per posting: 8-bit lower bound of sums32[row] << 8 | signature bits 0..7
     ds::DeviceBuffer<float> idf32;         // [n_columns]
-    ds::DeviceBuffer<float> sums32;        // [n_truth]
+    ds::DeviceBuffer<float> sums32;        // [n_truth] in INTERNAL row order (rows sorted by sums32; word 6 of a row record = the caller's row)
     ds::DeviceBuffer<float> tile_sums_min; // [n_tiles] min(sums32) over the rows of each tile
+    ds::DeviceBuffer<float> tile_sums_max; // [n_tiles] max(sums32) over the rows of each tile
     ds::DeviceBuffer<uint32_t> signature;  // [n_truth][8] one 32-byte record per row, ONE cache line per refined row: words 0..3 =
                                            // signature (bit g = row is in the posting list of the g-th densest column), word 4 =
                                            // sums32 bits, word 5 = duplicate rank (below), words 6..7 unused
     ds::DeviceBuffer<int8_t> sig_column;   // [n_columns] signature bit of a column, -1 for all but the 128 densest
     // duplicate rank of a row (word 5 of its record): rows with the same column set and sums32 bits but a larger index (saturating)
+    bool rows_sorted = false;              // internal row order ascends with sums32 (ds_index_create, DS_SORT_ROWS != 0)
     bool literal_only = false;             // idf32 / sums32 hold negative or non-finite values: the bounds of the fast kernel
                                            // do not apply, every query takes the literal kernel
     ds::DeviceBuffer<unsigned char> kernel_args;  // the fast kernel's argument block (read through the constant address space)

@@ -194,10 +194,11 @@ struct IndexImage {
     int64_t n_tiles = 0, tile_rows = 0, nnz = 0;
     uint64_t quads = 0;
     float sums_min = 0.f;
-    bool literal_only = false;
+    bool literal_only = false, rows_sorted = false;
     std::vector<uint32_t> col_ptr, records;
     std::vector<uint16_t> postings, posting_sums;
-    std::vector<float> tile_sums_min;
+    std::vector<float> tile_sums_min, tile_sums_max;
+    std::vector<float> sums;      // sums32 in internal row order (what the kernels index)
     std::vector<int8_t> sig_column;
 };
 
@@ -237,10 +238,84 @@ int build_index_image(const int64_t *rowptr, const int32_t *truth_idx, const flo
     };
     ds::FirstError error;
 
-    // pass 1 (threaded over columns): postings per (column, tile) -> quads, validating the lists; then the offsets
-    std::vector<uint32_t> col_ptr(static_cast<size_t>(V * stride), 0u);
     for (int64_t g = 0; g < V; ++g)
         DS_REQUIRE(rowptr[g + 1] >= rowptr[g], "ds_index_create: rowptr not monotone at column %lld", (long long)g);
+    // ---- internal row order: the truth rows are visited in ascending order of sums32 (ties: ascending
+    // row index).  A tile then spans a narrow range of sums32, which makes the row-independent bound of a tile nearly as
+    // sharp as a per-row one, lets a query start with the tiles whose rows can score highest (sums32 ~ its
+    // max_intersection_possible) and skip whole tiles whose rows cannot reach the running threshold at all
+    // (jaccard <= min(sums, maxint) / max(sums, maxint)).  Results are ORIGINAL row indexes: every row record carries
+    // its own (word 6) and fast_arg_top_k's "k largest row indexes" is decided on those.  DS_SORT_ROWS=0 keeps the
+    // caller's order (A/B measurements).
+    std::vector<int32_t> original(static_cast<size_t>(N));
+    std::vector<int32_t> permuted_idx;
+    std::vector<float> sums_internal(static_cast<size_t>(N));
+    const char *sort_switch = getenv("DS_SORT_ROWS");
+    const bool sort_rows = sort_switch == nullptr || atoi(sort_switch) != 0;
+    if (sort_rows) {
+        // the caller's lists are validated before they are permuted (pass 1 below then sees lists that are valid by construction)
+        ds::parallel_dynamic(V, 32, threads, [&](int, int64_t column_begin, int64_t column_end) {
+            for (int64_t g = column_begin; g < column_end; ++g) {
+                int64_t previous = -1;
+                for (int64_t p = rowptr[g]; p < rowptr[g + 1]; ++p) {
+                    if (!(truth_idx[p] > previous && truth_idx[p] < N)) {
+                        error.raise("ds_index_create: posting list of column %lld is not strictly ascending within [0, N)",
+                                    (long long)g);
+                        return;
+                    }
+                    previous = truth_idx[p];
+                }
+            }
+        });
+        DS_REQUIRE(!error.failed(), "%s", error.message());
+        // stable LSD radix sort of (order-preserving key of sums32, row): 11 + 11 + 10 bits
+        auto key_of = [&](int64_t t) {
+            uint32_t bits;
+            std::memcpy(&bits, &sums32[t], sizeof(bits));
+            return bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);  // float order as unsigned order
+        };
+        std::vector<int32_t> other(static_cast<size_t>(N));
+        for (int64_t t = 0; t < N; ++t) original[static_cast<size_t>(t)] = static_cast<int32_t>(t);
+        const int shifts[3] = {0, 11, 22}, widths[3] = {11, 11, 10};
+        for (int pass = 0; pass < 3; ++pass) {
+            const uint32_t buckets = 1u << widths[pass], mask = buckets - 1u;
+            std::vector<int64_t> start(buckets + 1, 0);
+            for (int64_t i = 0; i < N; ++i) ++start[((key_of(original[static_cast<size_t>(i)]) >> shifts[pass]) & mask) + 1];
+            for (uint32_t d = 0; d < buckets; ++d) start[d + 1] += start[d];
+            for (int64_t i = 0; i < N; ++i) {
+                const int32_t t = original[static_cast<size_t>(i)];
+                other[static_cast<size_t>(start[(key_of(t) >> shifts[pass]) & mask]++)] = t;
+            }
+            original.swap(other);
+        }
+        std::vector<int32_t> &position = other;  // original row -> internal row
+        ds::parallel_ranges(N, threads, [&](int, int64_t begin, int64_t end) {
+            for (int64_t i = begin; i < end; ++i) {
+                position[static_cast<size_t>(original[static_cast<size_t>(i)])] = static_cast<int32_t>(i);
+                sums_internal[static_cast<size_t>(i)] = sums32[original[static_cast<size_t>(i)]];
+            }
+        });
+        permuted_idx.resize(static_cast<size_t>(nnz));
+        ds::parallel_dynamic(V, 8, threads, [&](int, int64_t column_begin, int64_t column_end) {
+            for (int64_t g = column_begin; g < column_end; ++g) {
+                int32_t *list = permuted_idx.data() + rowptr[g];
+                const int64_t length = rowptr[g + 1] - rowptr[g];
+                for (int64_t p = 0; p < length; ++p) list[p] = position[static_cast<size_t>(truth_idx[rowptr[g] + p])];
+                std::sort(list, list + length);
+            }
+        });
+        truth_idx = permuted_idx.data();
+        sums32 = sums_internal.data();
+        phase("rows sorted by sums32");
+    } else {
+        for (int64_t t = 0; t < N; ++t) {
+            original[static_cast<size_t>(t)] = static_cast<int32_t>(t);
+            sums_internal[static_cast<size_t>(t)] = sums32[t];
+        }
+    }
+
+    // pass 1 (threaded over columns): postings per (column, tile) -> quads, validating the lists; then the offsets
+    std::vector<uint32_t> col_ptr(static_cast<size_t>(V * stride), 0u);
     ds::parallel_dynamic(V, 32, threads, [&](int, int64_t column_begin, int64_t column_end) {
         for (int64_t g = column_begin; g < column_end; ++g) {
             uint32_t *row = col_ptr.data() + g * stride;
@@ -278,13 +353,17 @@ int build_index_image(const int64_t *rowptr, const int32_t *truth_idx, const flo
     }
     DS_REQUIRE(quads < 0xfffffff0ull, "ds_index_create: more than 2^32 posting quads");
     phase("list pointers");
-    std::vector<float> tile_sums_min(static_cast<size_t>(n_tiles), 0.f);
+    std::vector<float> tile_sums_min(static_cast<size_t>(n_tiles), 0.f), tile_sums_max(static_cast<size_t>(n_tiles), 0.f);
     ds::parallel_dynamic(n_tiles, 16, threads, [&](int, int64_t tile_begin, int64_t tile_end) {
         for (int64_t b = tile_begin; b < tile_end; ++b) {
             const int64_t first = b * tile_rows, last = std::min<int64_t>(N, first + tile_rows);
-            float lowest = sums32[first];
-            for (int64_t t = first + 1; t < last; ++t) lowest = std::min(lowest, sums32[t]);
+            float lowest = sums32[first], highest = sums32[first];
+            for (int64_t t = first + 1; t < last; ++t) {
+                lowest = std::min(lowest, sums32[t]);
+                highest = std::max(highest, sums32[t]);
+            }
             tile_sums_min[static_cast<size_t>(b)] = lowest;
+            tile_sums_max[static_cast<size_t>(b)] = highest;
         }
     });
     float sums_min = sums32[0];
@@ -377,6 +456,7 @@ int build_index_image(const int64_t *rowptr, const int32_t *truth_idx, const flo
             uint32_t *record = records.data() + static_cast<size_t>(t) * ds::kRowRecordWords;
             std::memcpy(&record[4], &sums32[t], sizeof(float));
             record[5] = dup_rank[static_cast<size_t>(t)];
+            record[6] = static_cast<uint32_t>(original[static_cast<size_t>(t)]);  // the caller's row index: what the kernels return
         }
     });
     image.n_tiles = n_tiles;
@@ -385,11 +465,14 @@ int build_index_image(const int64_t *rowptr, const int32_t *truth_idx, const flo
     image.quads = quads;
     image.sums_min = sums_min;
     image.literal_only = literal_only;
+    image.rows_sorted = sort_rows;
     image.col_ptr.swap(col_ptr);
     image.records.swap(records);
     image.postings.swap(postings);
     image.posting_sums.swap(posting_sums);
     image.tile_sums_min.swap(tile_sums_min);
+    image.tile_sums_max.swap(tile_sums_max);
+    image.sums.swap(sums_internal);
     image.sig_column.swap(sig_column);
     return DS_OK;
 }
@@ -431,6 +514,7 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     index->n_quads = static_cast<int64_t>(quads);
     index->sums_min = sums_min;
     index->literal_only = literal_only;
+    index->rows_sorted = image.rows_sorted;
     int status = index->col_ptr.upload(col_ptr.data(), col_ptr.size());
     if (status == DS_OK) status = index->postings.upload(postings.data(), postings.size());
     if (status == DS_OK && postings.empty()) status = index->postings.allocate(4);
@@ -439,10 +523,11 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     if (status == DS_OK) status = index->idf32.upload(idf32, static_cast<size_t>(V));
     if (status == DS_OK) {  // padded so that the dense scan may read eight rows at once near the end
         std::vector<float> padded(static_cast<size_t>(N) + 8, 0.f);
-        std::memcpy(padded.data(), sums32, sizeof(float) * static_cast<size_t>(N));
+        std::memcpy(padded.data(), image.sums.data(), sizeof(float) * static_cast<size_t>(N));
         status = index->sums32.upload(padded.data(), padded.size());
     }
     if (status == DS_OK) status = index->tile_sums_min.upload(tile_sums_min.data(), tile_sums_min.size());
+    if (status == DS_OK) status = index->tile_sums_max.upload(image.tile_sums_max.data(), image.tile_sums_max.size());
     if (status == DS_OK) status = index->signature.upload(records.data(), records.size());
     if (status == DS_OK) status = index->sig_column.upload(sig_column.data(), sig_column.size());
     if (status == DS_OK) status = index->control.allocate(ds::kControlWords);
@@ -484,7 +569,8 @@ int ds_index_image_digest(const int64_t *rowptr, const int32_t *truth_idx, const
     digest[1] = fnv(image.postings.data(), image.postings.size() * 2);
     digest[2] = fnv(image.posting_sums.data(), image.posting_sums.size() * 2);
     digest[3] = fnv(image.records.data(), image.records.size() * 4);
-    digest[4] = fnv(image.tile_sums_min.data(), image.tile_sums_min.size() * 4);
+    digest[4] = fnv(image.tile_sums_min.data(), image.tile_sums_min.size() * 4) ^ fnv(image.tile_sums_max.data(), image.tile_sums_max.size() * 4) ^
+                fnv(image.sums.data(), image.sums.size() * 4);
     digest[5] = fnv(image.sig_column.data(), image.sig_column.size());
     digest[6] = image.quads;
     digest[7] = image.literal_only ? 1u : 0u;

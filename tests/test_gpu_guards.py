@@ -143,8 +143,11 @@ def _redo_problem(tied):
 
 
 @pytest.mark.parametrize("tied", [False, True])
-def test_candidate_overflow_inside_an_epoch_is_redone_and_counted(oracle, tied):
+def test_candidate_overflow_inside_an_epoch_is_redone_and_counted(oracle, tied, monkeypatch):
     import doppel_speller_amd as ds
+    # the scenario places its rows tile by tile: the index keeps the caller's row order (ds_index_create sorts the rows by
+    # sums32 otherwise, and a query then starts at the tile of its own sums32)
+    monkeypatch.setenv("DS_SORT_ROWS", "0")
     rowptr, truth_idx, idf32, sums32, q_rowptr, q_cols, q_maxint, k = _redo_problem(tied)
     index = ds.TruthIndex(rowptr, truth_idx, idf32, sums32)
     assert index.info()["tile_rows"] == NARROW_TILE
@@ -156,11 +159,16 @@ def test_candidate_overflow_inside_an_epoch_is_redone_and_counted(oracle, tied):
     expected = oracle.jaccard_topk(rowptr, truth_idx, idf32, sums32, q_rowptr, q_cols, q_maxint, k)
     assert np.array_equal(rows, expected)
     assert stats["error_queries"] == 0
-    if tied:     # every redo overflows again: bounded retries, then the literal kernel answers
-        assert stats["sparse_redos"] >= 3 and stats["dense_queries"] == 1
-        assert stats["dense_reasons"]["overflow_sparse"] == 1
-    else:        # one redo under the tightened threshold is enough
+    if tied:     # no threshold and no admission floor separates a thousand equal rows: the literal kernel answers
+        assert stats["sparse_redos"] >= 1 and stats["dense_queries"] == 1
+        assert stats["dense_reasons"]["overflow_sparse"] + stats["dense_reasons"]["ties"] == 1
+    else:        # the epoch is repeated under the tightened threshold and the admission floor, and fits
         assert 1 <= stats["sparse_redos"] <= 3 and stats["dense_queries"] == 0
+
+    # the same problems with the rows in sums32 order (the default): whatever path they take, the answers are the reference's
+    monkeypatch.setenv("DS_SORT_ROWS", "1")
+    index = ds.TruthIndex(rowptr, truth_idx, idf32, sums32)
+    assert np.array_equal(index.top_k(q_rowptr, q_cols, q_maxint, k), expected)
 
 
 def test_near_ties_beyond_the_literal_kernels_buffer_are_answered_by_the_row_scan(oracle):
