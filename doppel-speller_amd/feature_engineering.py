@@ -51,6 +51,40 @@ def get_truth_words_counts(title, words_counter):
     return out
 
 
+def _optional_pointer(array):
+    return ctypes.c_void_p(array.ctypes.data) if array is not None else ctypes.c_void_p(0)
+
+
+def encode_collection(flat, offsets, code_of=None, stride=MAX_CHARACTERS_ALLOWED_IN_THE_TITLE):
+    """encode_title (feature_engineering.py:298-307) for a whole collection in one native, threaded call
+    (ds_encode_titles): titles = flat[offsets[i]:offsets[i + 1]] (bytes), code_of = uint8[256] character -> code table (None:
+    the bytes are codes already) -> (uint8[n, stride], uint8[n])."""
+    count = offsets.shape[0] - 1
+    enc = np.empty((count, stride), dtype=np.uint8)
+    lengths = np.empty(count, dtype=np.uint8)
+    flat = np.ascontiguousarray(flat, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    _lib.check(_lib.lib().ds_encode_titles(_optional_pointer(flat), _optional_pointer(offsets), count,
+                                           _optional_pointer(code_of), stride, _optional_pointer(enc),
+                                           _optional_pointer(lengths)), "ds_encode_titles")
+    return enc, lengths
+
+
+def truth_word_counts(flat, offsets, separators=(SPACE_CODE,)):
+    """get_truth_words_counts (feature_engineering.py:309-319) over the counter of common.py:140-142 for a whole truth
+    collection in one native, threaded call (ds_truth_word_counts): uint32[n, 15].  separators: the byte values str.split()
+    splits on (the space code for encoded titles; ASCII white space for text)."""
+    count = offsets.shape[0] - 1
+    out = np.empty((count, NUMBER_OF_WORDS_FEATURES), dtype=np.uint32)
+    table = np.zeros(256, dtype=np.uint8)
+    table[list(separators)] = 1
+    flat = np.ascontiguousarray(flat, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    _lib.check(_lib.lib().ds_truth_word_counts(_optional_pointer(flat), _optional_pointer(offsets), count,
+                                               _optional_pointer(table), _optional_pointer(out)), "ds_truth_word_counts")
+    return out
+
+
 def construct_features(title_number_of_characters, truth_number_of_characters, title, title_truth,
                        truth_words_counts, space_code, number_of_truth_titles, dummy, response):
     """

@@ -36,7 +36,8 @@ from types import SimpleNamespace
 
 import numpy as np
 
-from .feature_engineering import ALLOWED_CHARACTERS, MAX_CHARACTERS_ALLOWED_IN_THE_TITLE, NUMBER_OF_WORDS_FEATURES
+from .feature_engineering import (ALLOWED_CHARACTERS, MAX_CHARACTERS_ALLOWED_IN_THE_TITLE, NUMBER_OF_WORDS_FEATURES,
+                                  encode_collection, truth_word_counts)  # noqa: F401 - re-exported for tests
 
 DEFAULT_SEED = 20260101
 _BASE = len(ALLOWED_CHARACTERS)  # 38 codes: '-'=0 (fill), ' '=1, a-z=2..27, 0-9=28..37
@@ -228,33 +229,6 @@ def _from_strings(titles):
         table[ord(ch)] = code
     flat = table[np.frombuffer("".join(titles).encode("ascii"), dtype=np.uint8)]
     return flat, offsets
-
-
-def encode_collection(flat, offsets, code_of=None, stride=MAX_CHARACTERS_ALLOWED_IN_THE_TITLE):
-    """encode_title for a whole collection through the product's ds_encode_titles: (uint8[n, stride], uint8[n])."""
-    from . import _lib
-    count = offsets.shape[0] - 1
-    enc = np.empty((count, stride), dtype=np.uint8)
-    lengths = np.empty(count, dtype=np.uint8)
-    flat = np.ascontiguousarray(flat, dtype=np.uint8)
-    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-    _lib.check(_lib.lib().ds_encode_titles(_ptr(flat), _ptr(offsets), count, _ptr(code_of), stride, _ptr(enc),
-                                           _ptr(lengths)), "ds_encode_titles")
-    return enc, lengths
-
-
-def truth_word_counts(flat, offsets, separators=(_SPACE,)):
-    """get_truth_words_counts for a whole collection through the product's ds_truth_word_counts: uint32[n, 15]."""
-    from . import _lib
-    count = offsets.shape[0] - 1
-    out = np.empty((count, NUMBER_OF_WORDS_FEATURES), dtype=np.uint32)
-    table = np.zeros(256, dtype=np.uint8)
-    table[list(separators)] = 1
-    flat = np.ascontiguousarray(flat, dtype=np.uint8)
-    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-    _lib.check(_lib.lib().ds_truth_word_counts(_ptr(flat), _ptr(offsets), count, _ptr(table), _ptr(out)),
-               "ds_truth_word_counts")
-    return out
 
 
 def make_truth(n_truth, seed=DEFAULT_SEED, vocabulary_size=None):
