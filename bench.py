@@ -469,7 +469,7 @@ def main():
             "dense_path_queries": int(stats["dense_queries"]), "exact_candidates_per_query":
                 stats["exact_candidates"] / max(1, per_gpu),
             "verified_queries": checked, "selections_per_query": stats["selections"] / max(1, per_gpu),
-            "dense_reasons": stats["dense_reasons"],
+            "dense_reasons": stats["dense_reasons"], "sparse_redos": int(stats["sparse_redos"]),
             "tiles": {"sparse": stats["sparse_tiles"], "dense": stats["dense_tiles"]},
             "skipped_columns_per_query": stats["skipped_columns"] / max(1, per_gpu),
             "roofline": roofline,

@@ -278,14 +278,29 @@ int build_index_image(const int64_t *rowptr, const int32_t *truth_idx, const flo
         for (int64_t t = 0; t < N; ++t) original[static_cast<size_t>(t)] = static_cast<int32_t>(t);
         const int shifts[3] = {0, 11, 22}, widths[3] = {11, 11, 10};
         for (int pass = 0; pass < 3; ++pass) {
+            // threaded and stable: every thread counts the digits of its contiguous range, the counts are turned into write
+            // positions bucket by bucket and, within a bucket, thread by thread, and every thread scatters its range in order
             const uint32_t buckets = 1u << widths[pass], mask = buckets - 1u;
-            std::vector<int64_t> start(buckets + 1, 0);
-            for (int64_t i = 0; i < N; ++i) ++start[((key_of(original[static_cast<size_t>(i)]) >> shifts[pass]) & mask) + 1];
-            for (uint32_t d = 0; d < buckets; ++d) start[d + 1] += start[d];
-            for (int64_t i = 0; i < N; ++i) {
-                const int32_t t = original[static_cast<size_t>(i)];
-                other[static_cast<size_t>(start[(key_of(t) >> shifts[pass]) & mask]++)] = t;
-            }
+            std::vector<int64_t> start(static_cast<size_t>(threads) * buckets, 0);
+            ds::parallel_ranges(N, threads, [&](int thread, int64_t begin, int64_t end) {
+                int64_t *mine = start.data() + static_cast<size_t>(thread) * buckets;
+                for (int64_t i = begin; i < end; ++i) ++mine[(key_of(original[static_cast<size_t>(i)]) >> shifts[pass]) & mask];
+            });
+            int64_t position = 0;
+            for (uint32_t d = 0; d < buckets; ++d)
+                for (int thread = 0; thread < threads; ++thread) {
+                    int64_t &slot = start[static_cast<size_t>(thread) * buckets + d];
+                    const int64_t here = slot;
+                    slot = position;
+                    position += here;
+                }
+            ds::parallel_ranges(N, threads, [&](int thread, int64_t begin, int64_t end) {
+                int64_t *mine = start.data() + static_cast<size_t>(thread) * buckets;
+                for (int64_t i = begin; i < end; ++i) {
+                    const int32_t t = original[static_cast<size_t>(i)];
+                    other[static_cast<size_t>(mine[(key_of(t) >> shifts[pass]) & mask]++)] = t;
+                }
+            });
             original.swap(other);
         }
         std::vector<int32_t> &position = other;  // original row -> internal row

@@ -112,20 +112,22 @@ def test_bench_on_distinct_devices_exits_non_zero_when_rccl_cannot_start():
     assert "RCCL could not be initialised" in result.stderr
 
 
-def test_c5_rehearsal_two_ranks_share_one_published_workload():
-    """C5's flow with two rank processes on the box's one GPU: rank 0 generates the WHOLE workload once (5M truth titles
-    here, top-100 + features) and publishes it in shared memory, both ranks map it, build the replicated
-    index and take UNEVEN query shards (10000 / 10001); the rows are gathered through the host communicator."""
+@pytest.mark.parametrize("config,k", [("C5", 100), ("C4", 50)])
+def test_strong_scaling_rehearsal_two_ranks_share_one_published_workload(config, k):
+    """C4's / C5's flow with two rank processes on the box's one GPU: rank 0 generates the WHOLE workload once (5M truth
+    titles, top-50 / top-100 + features) and publishes it in shared memory, both ranks map it, build the replicated
+    index and take UNEVEN query shards (10000 / 10001: a fixed number of queries in all, strong scaling); the rows are
+    gathered through the host communicator."""
     env = dict(os.environ, DS_BENCH_SAME_DEVICE="1")
     env.pop("WORLD_SIZE", None)
-    result = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C5", "--truth",
+    result = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config, "--truth",
                              "5000000", "--queries", "20001", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0",
                              "--check", "16", "--host-communicator"], env=env, capture_output=True, text=True,
                             timeout=1200)
     assert result.returncode == 0, result.stderr[-3000:]
     line = json.loads(result.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["queries"] == 20001
-    assert line["config"]["queries_per_gpu"] == 10000 and line["config"]["k"] == 100 and line["verified_queries"] == 16
+    assert line["config"]["queries_per_gpu"] == 10000 and line["config"]["k"] == k and line["verified_queries"] == 16
     assert line["roofline"]["geometry"] == "narrow" and line["value"] > 0     # 5M rows: narrow tiles (wide above 10M)
     assert not [name for name in os.listdir("/dev/shm") if name.startswith("ds_bench_")]     # rank 0 cleaned up
 
