@@ -470,6 +470,7 @@ def main():
                 stats["exact_candidates"] / max(1, per_gpu),
             "verified_queries": checked, "selections_per_query": stats["selections"] / max(1, per_gpu),
             "dense_reasons": stats["dense_reasons"], "sparse_redos": int(stats["sparse_redos"]),
+            "bounds_record": [int(x) for x in stats["bounds_record"]],   # all 0 unless a -DDS_BOUNDS_CHECK build caught an index
             "tiles": {"sparse": stats["sparse_tiles"], "dense": stats["dense_tiles"]},
             "skipped_columns_per_query": stats["skipped_columns"] / max(1, per_gpu),
             "roofline": roofline,
@@ -490,8 +491,8 @@ def main():
             line["next_rows"] = next_rows
         if any(stats["phase_cycles"].values()):  # library built with -DDS_DIAGNOSTICS and DS_PHASE_TIMERS=1
             line["diagnostics"] = {"phase_cycles": stats["phase_cycles"], "wave_refines": stats["refines"],
-                                   "raw_entries_sparse": stats["raw_entries_sparse"],
-                                   "bounds_record": stats.get("bounds_record")}
+                                   "raw_entries": stats["raw_entries"], "refine_survivors": stats["refine_survivors"],
+                                   "raw_entries_sparse": stats["raw_entries_sparse"]}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(workload, k, args.cpu_seconds)
         print(json.dumps(line), flush=True)
