@@ -257,6 +257,11 @@ def main():
     if world == 1:
         stop = heartbeat("generating the workload")
         workload = synth.make_workload(truth, total_queries, seed=args.seed)
+        experiment = os.environ.get("DS_EXPERIMENT_QUERY_ORDER", "")  # tuning experiments only (profiles/r03_tuning.txt)
+        if experiment:
+            key = workload.q_maxint if "maxint" in experiment else np.diff(workload.q_rowptr)
+            order = np.argsort(key, kind="stable")
+            workload = synth.reorder_queries(workload, order[::-1] if experiment.endswith("desc") else order)
         stop()
     else:
         import shutil

@@ -140,6 +140,9 @@ struct ds_index {
     ds::DeviceBuffer<int32_t> control;     // [16] work-queue head, slow-list length, error count, counters
     ds::DeviceBuffer<int32_t> status;      // per-query status of the last call (grown on demand)
     ds::DeviceBuffer<int32_t> slow_list;   // query ids routed to the exact dense kernel
+    ds::DeviceBuffer<int32_t> take_order;  // the order in which the fast kernel's work queue hands out the queries of the last
+                                           // call: most columns first (longest-processing-time-first keeps the launch's tail short)
+    ds::DeviceBuffer<int32_t> order_bins;  // [2][136] counting sort of the queries by their number of columns: counts, cursors
     ds::DeviceBuffer<unsigned long long> phase;  // diagnostic phase timers (DS_PHASE_TIMERS=1)
     hipStream_t stream = nullptr;          // used by the host-pointer entry points
     int compute_units = 256;

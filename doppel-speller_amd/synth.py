@@ -273,6 +273,20 @@ def make_workload(n_truth, n_queries, seed=DEFAULT_SEED, vocabulary_size=None, q
         t_flat=t_flat, t_off=t_off, q_flat=q_flat, q_off=q_off, problem=problem)
 
 
+def reorder_queries(w, order):
+    """The workload with its queries in another order (query i of the result = query order[i]): experiments on the order in
+    which a launch takes its queries.  The text of the queries (q_flat / q_off) is dropped."""
+    order = np.asarray(order, dtype=np.int64)
+    lengths = np.diff(w.q_rowptr)[order]
+    rowptr = np.concatenate(([0], np.cumsum(lengths))).astype(np.int64)
+    take = np.repeat(w.q_rowptr[:-1][order] - rowptr[:-1], lengths) + np.arange(rowptr[-1])
+    fields = dict(vars(w))
+    fields.update(q_rowptr=rowptr, q_cols=np.ascontiguousarray(w.q_cols[take]), q_maxint=np.ascontiguousarray(w.q_maxint[order]),
+                  q_enc=np.ascontiguousarray(w.q_enc[order]), q_len=np.ascontiguousarray(w.q_len[order]),
+                  actual_row=w.actual_row[order], q_flat=None, q_off=None)
+    return SimpleNamespace(**fields)
+
+
 _PUBLISHED = ("rowptr", "truth_idx", "idf32", "idf64", "sums32", "q_rowptr", "q_cols", "q_maxint", "t_enc", "t_len",
               "t_counts", "q_enc", "q_len", "title_id", "actual_row", "t_flat", "t_off", "q_flat", "q_off")
 
