@@ -449,3 +449,29 @@ def test_a_column_listed_twice_in_a_query(oracle, k):
     status = index.status(200)
     assert np.array_equal(status == 1, np.array(repeated)) or (status[~np.array(repeated)] <= 1).all()
     assert (status[np.array(repeated)] == 1).all() and index.sync()["error_queries"] == 0
+
+
+@pytest.mark.parametrize("order", ["0", "1"])
+def test_work_queue_order_does_not_change_answers(oracle, monkeypatch, order):
+    """The fast kernel takes the queries with most columns first (a device-side counting sort, DS_QUERY_ORDER=0 switches it
+    off): every query is answered exactly once either way, including queries without columns and with > 128 columns."""
+    monkeypatch.setenv("DS_QUERY_ORDER", order)
+    rng = np.random.RandomState(77)
+    problem = _random_problem(rng, 30000, 1500, 700, mean_cols=12)
+    n_columns = problem["rowptr"].shape[0] - 1
+    q_cols = [problem["q_cols"][problem["q_rowptr"][q]:problem["q_rowptr"][q + 1]] for q in range(700)]
+    q_cols[3] = np.zeros(0, dtype=np.int32)                                             # no columns at all
+    wide = np.sort(rng.choice(n_columns, 200, replace=False)).astype(np.int32)          # more than the fast kernel takes
+    q_cols[5] = wide[problem["idf32"][wide] != 0]
+    problem["q_rowptr"] = np.concatenate(([0], np.cumsum([len(c) for c in q_cols]))).astype(np.int64)
+    problem["q_cols"] = np.concatenate(q_cols).astype(np.int32)
+    idf64 = problem["idf32"].astype(np.float64)
+    maxint = []
+    for c in q_cols:
+        total = 0.0
+        for value in idf64[c]:
+            total = total + float(value)
+        maxint.append(max(total, 1e-3))
+    problem["q_maxint"] = np.array(maxint)
+    index = _check(oracle, problem, 10)
+    assert index.sync()["error_queries"] == 0

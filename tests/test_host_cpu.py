@@ -221,3 +221,18 @@ def test_bench_configurations_follow_baseline_json():
     with open(os.path.join(ROOT, "BASELINE.json")) as handle:
         configs = json.load(handle)["configs"]
     assert "100k synthetic queries" in configs[1] and "1M queries" in configs[2] and "8M queries" in configs[3]
+
+
+def test_reorder_queries_keeps_every_query():
+    """synth.reorder_queries (tuning experiments on the order of a launch's queries) permutes every per-query array alike."""
+    import doppel_speller_amd as ds  # noqa: F401
+    from doppel_speller_amd import synth
+    w = synth.make_workload(4000, 300)
+    order = np.argsort(w.q_maxint, kind="stable")[::-1]
+    r = synth.reorder_queries(w, order)
+    assert r.q_rowptr[-1] == w.q_rowptr[-1] and np.array_equal(np.sort(r.q_maxint), np.sort(w.q_maxint))
+    for i in (0, 17, 299):
+        q = order[i]
+        assert np.array_equal(r.q_cols[r.q_rowptr[i]:r.q_rowptr[i + 1]], w.q_cols[w.q_rowptr[q]:w.q_rowptr[q + 1]])
+        assert r.q_maxint[i] == w.q_maxint[q] and np.array_equal(r.q_enc[i], w.q_enc[q]) and r.q_len[i] == w.q_len[q]
+        assert r.actual_row[i] == w.actual_row[q]
