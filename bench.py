@@ -24,7 +24,7 @@ the max over ranks go through a TCP rendezvous.  Rank 0 prints ONE JSON line.
 Extra objects on the line:
   roofline      ds_jaccard_topk_kernel against the HBM roofline: achieved = bytes the kernel REQUESTS from global
                 memory per launch (counted by a second instantiation of the kernel in one untimed launch: postings,
-                per-posting info, sums32 of dense scans, list pointers) / its average launch duration (HIP events
+                per-posting info, list pointers, row records of the refined rows) / its average launch duration (HIP events
                 on the launch stream); `traffic` = 2 * FETCH_SIZE + WRITE_SIZE of profiles/pmc_latest.json when that
                 file was measured on this build and workload; `bound_model` = the kernel's shares of VALU issue, LDS and HBM time from the same
                 counters; `speedup_over_reference_hbm_floor` = the bytes the REFERENCE's algorithm would read
@@ -412,8 +412,8 @@ def main():
                     "avg_launch_ms": mean_topk, "geometry": "narrow" if pipeline.index.info()["tile_rows"] == 12288 else "wide",
                     "bytes_per_query": requested / max(1, per_gpu),
                     "note": "`achieved` / `frac` use requested_bytes_per_launch = what THIS kernel requests from global "
-                            "memory per launch (2-byte postings of the traversed lists + per-posting row info, sums32 of "
-                            "the dense scans, list pointers, per-column setup, refinement gathers, exact-stage probes), "
+                            "memory per launch (2-byte postings of the traversed lists + per-posting row info, list pointers, "
+                            "per-column setup, refinement gathers, exact-stage probes; dense scans read nothing), "
                             "counted by a second instantiation of the kernel in one extra untimed launch.  "
                             "survey_8d_bytes_per_launch = SURVEY.md 8d's B_jac, what the REFERENCE's algorithm reads: the "
                             "kernel skips most of it (MaxScore), so frac_on_survey_8d_bytes exceeds 1 -- a speed-up over "
