@@ -1,5 +1,7 @@
 """Next row f-3: the native index build (`ds_problem_create`, host code in libdoppel_amd.so) against the Python
 restatement of `MatchMaker.__init__` (which itself is pinned by the golden vectors) -- no GPU needed."""
+import os
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -195,3 +197,22 @@ def test_encoders_for_whole_collections_against_the_per_title_functions(monkeypa
             assert lengths[row] == len(titles[row])
             assert np.array_equal(counts[row], get_truth_words_counts(titles[row], counter)), (row, titles[row])
     assert counts[5, 0] == counter["bv"] and counts[5, 1] == counter["bv"] and counts[5, 4] == 0
+
+
+def test_fast_kernel_contains_no_function_call(tmp_path):
+    """Round 3's diagnostics-build fault (profiles/r03_failure_causes.md (c)) went away when the one device function the
+    compiler had not inlined was: the Jaccard kernels keep ~120 spilled scalar registers in VGPR lanes and must not call
+    out.  The generated ISA of the narrow geometry holds no s_swappc_b64."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "narrow.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", '-DDS_BUILD_ID="t"',
+                    "-I", os.path.join(root, "include"), "-S", "--cuda-device-only",
+                    os.path.join(root, "doppel-speller_amd", "csrc", "ds_jaccard_narrow.hip"), "-o", str(out)],
+                   check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    assert "ds_jaccard_topk_kernel" in text
+    assert "s_swappc_b64" not in text and "s_setpc_b64" not in text
