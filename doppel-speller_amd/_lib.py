@@ -132,6 +132,7 @@ def _declare(handle):
         "ds_construct_features_indexed_device": [p, p, p, p, c.c_int64, c.c_int32, c.c_uint8, c.c_uint32, c.c_int64,
                                                  p, p],
         "ds_levenshtein_ratio_batch": [p, p, p, p, c.c_int64, c.c_int, c.c_int, p],
+        "ds_levenshtein_ratio": [p, c.c_int, p, c.c_int],
         "ds_close_matches": [p, p, p, c.c_int32, c.c_int64, c.c_uint8, p, c.c_int32, p, p],
         "ds_close_matches_device": [p, p, p, c.c_int64, c.c_int32, c.c_int64, c.c_uint8, p, c.c_int32, p, p, p],
         "ds_remaining_pairs_device": [p, p, c.c_int64, c.c_int32, c.c_int64, p, p, p, p],
@@ -177,7 +178,7 @@ EXPORTED_SYMBOLS = (
     "ds_index_duplicate_ranks", "ds_index_image_digest", "ds_index_option",
     "ds_index_info", "ds_jaccard_topk", "ds_jaccard_topk_device", "ds_jaccard_sync", "ds_jaccard_status", "ds_construct_features",
     "ds_titles_create", "ds_titles_destroy", "ds_construct_features_indexed", "ds_construct_features_indexed_device",
-    "ds_levenshtein_ratio_batch", "ds_close_matches", "ds_close_matches_device", "ds_remaining_pairs_counts_size", "ds_remaining_pairs_device",
+    "ds_levenshtein_ratio_batch", "ds_levenshtein_ratio", "ds_close_matches", "ds_close_matches_device", "ds_remaining_pairs_counts_size", "ds_remaining_pairs_device",
     "ds_select_matches_device", "ds_problem_create",
     "ds_problem_destroy", "ds_problem_info", "ds_problem_arrays", "ds_transform_titles", "ds_encode_titles", "ds_truth_word_counts", "ds_forest_create", "ds_forest_destroy",
     "ds_forest_predict", "ds_forest_predict_device", "ds_malloc", "ds_free", "ds_memcpy_h2d", "ds_memcpy_d2h", "ds_memset",

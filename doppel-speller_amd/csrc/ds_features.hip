@@ -16,8 +16,10 @@
 //     anti-diagonal DP with uint8 wrap-around, three diagonals staged in LDS, 64 cells per step.
 // All strings, masks and the reconstructed title live in LDS; HBM traffic is the title bytes in and 264 B out.
 #include <cmath>
+#include <mutex>
 
 #include "ds_common.h"
+#include "ds_host.h"
 
 namespace ds {
 
@@ -32,6 +34,8 @@ struct FeatureArgs {
     const uint32_t *t_counts;
     const int32_t *pair_q;  // nullable
     const int32_t *pair_t;  // nullable
+    const uint32_t *q_off;  // nullable: row i of the titles starts at q_enc + q_off[i] instead of q_enc + i * q_stride
+    const uint32_t *t_off;  //           (the packed staging of the host-pointer entry point ships only the titles' own bytes)
     float *out;
     int64_t q_stride, t_stride;
     int64_t n_q, n_t;       // table sizes (bounds for indexes)
@@ -255,8 +259,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(
             continue;
         }
         const int lq = a.q_len[qi], lt = a.t_len[ti];                                      // :101-102
-        const uint8_t *gq = a.q_enc + qi * a.q_stride;
-        const uint8_t *gt = a.t_enc + ti * a.t_stride;
+        const uint8_t *gq = a.q_enc + (a.q_off ? static_cast<int64_t>(a.q_off[qi]) : qi * a.q_stride);
+        const uint8_t *gt = a.t_enc + (a.t_off ? static_cast<int64_t>(a.t_off[ti]) : ti * a.t_stride);
         wave_sync();
         // stage both strings; count spaces; squeeze the spaces out of the title (:104-108)
         int spaces_q = 0, spaces_t = 0, lw = 0;
@@ -606,6 +610,141 @@ __global__ void ds_close_best_kernel(CloseArgs a)
     a.best_row[q] = (where >= 0 && count == 1) ? a.pair_t[q * a.k + where] : -1;
 }
 
+
+// ---- host-pointer entry point: packed, pinned, chunked (see ds_construct_features below) -------------------------------
+constexpr int64_t kStageChunk = 16384;                                  // pairs per chunk
+constexpr int64_t kStageInBytes = kStageChunk * (2 + 8 + 4 * DS_WORDS + 2 * DS_MAX_CHARS);
+constexpr int kStageMaxSlots = 8;
+
+struct FeatureInputs {
+    const uint8_t *q_len, *t_len, *q_enc, *t_enc;
+    const uint32_t *t_counts;
+    uint8_t space_code;
+    uint32_t n_truth;
+    int64_t n, stride;
+    float *out;
+};
+
+struct FeatureSlot {
+    hipStream_t stream = nullptr;
+    unsigned char *h_in = nullptr, *d_in = nullptr;   // h_*: pinned host memory
+    float *h_out = nullptr, *d_out = nullptr;
+};
+
+struct FeatureStaging {
+    std::mutex mutex;   // one call at a time per process (the handles are documented as not thread-safe; this makes it safe)
+    int device = -1;
+    std::vector<FeatureSlot> slots;
+    int ensure(int wanted_device, int wanted_slots)
+    {
+        if (device != wanted_device) release();
+        device = wanted_device;
+        while (static_cast<int>(slots.size()) < wanted_slots) {
+            FeatureSlot slot;
+            DS_HIP(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
+            slots.push_back(slot);   // registered first: release() frees whatever of it got allocated
+            FeatureSlot &mine = slots.back();
+            DS_HIP(hipHostMalloc(reinterpret_cast<void **>(&mine.h_in), kStageInBytes, hipHostMallocDefault));
+            DS_HIP(hipHostMalloc(reinterpret_cast<void **>(&mine.h_out), kStageChunk * DS_FEATURES_COUNT * sizeof(float), hipHostMallocDefault));
+            DS_HIP(hipMalloc(reinterpret_cast<void **>(&mine.d_in), kStageInBytes));
+            DS_HIP(hipMalloc(reinterpret_cast<void **>(&mine.d_out), kStageChunk * DS_FEATURES_COUNT * sizeof(float)));
+        }
+        return DS_OK;
+    }
+    void release()
+    {
+        for (FeatureSlot &slot : slots) {
+            if (slot.h_in) (void)hipHostFree(slot.h_in);
+            if (slot.h_out) (void)hipHostFree(slot.h_out);
+            if (slot.d_in) (void)hipFree(slot.d_in);
+            if (slot.d_out) (void)hipFree(slot.d_out);
+            if (slot.stream) (void)hipStreamDestroy(slot.stream);
+        }
+        slots.clear();
+    }
+};
+
+static FeatureStaging &feature_staging()
+{
+    static FeatureStaging *staging = new FeatureStaging();   // never destroyed: no HIP calls from static destructors
+    return *staging;
+}
+
+static int launch_features(const FeatureArgs &args, int device, hipStream_t stream);
+
+// one chunk [first, first + m) through one slot; returns a status
+static int stage_chunk(const FeatureInputs &in, FeatureSlot &slot, int device, int64_t first, int64_t m)
+{
+    const int64_t m4 = (m + 3) & ~int64_t(3);
+    unsigned char *h = slot.h_in;
+    uint8_t *h_qlen = h, *h_tlen = h + m4;
+    uint32_t *h_qoff = reinterpret_cast<uint32_t *>(h + 2 * m4), *h_toff = reinterpret_cast<uint32_t *>(h + 6 * m4);
+    uint32_t *h_counts = reinterpret_cast<uint32_t *>(h + 10 * m4);
+    const int64_t chars_at = 10 * m4 + 4 * DS_WORDS * m4;
+    unsigned char *h_chars = h + chars_at;
+    std::memcpy(h_qlen, in.q_len + first, static_cast<size_t>(m));
+    std::memcpy(h_tlen, in.t_len + first, static_cast<size_t>(m));
+    std::memcpy(h_counts, in.t_counts + first * DS_WORDS, static_cast<size_t>(m) * DS_WORDS * sizeof(uint32_t));
+    uint32_t used = 0;
+    for (int64_t i = 0; i < m; ++i) {
+        const uint32_t lq = h_qlen[i], lt = h_tlen[i];
+        h_qoff[i] = used;
+        std::memcpy(h_chars + used, in.q_enc + (first + i) * in.stride, lq);
+        used += lq;
+        h_toff[i] = used;
+        std::memcpy(h_chars + used, in.t_enc + (first + i) * in.stride, lt);
+        used += lt;
+    }
+    DS_HIP(hipMemcpyAsync(slot.d_in, h, static_cast<size_t>(chars_at) + used, hipMemcpyHostToDevice, slot.stream));
+    FeatureArgs args{};
+    args.q_enc = slot.d_in + chars_at; args.t_enc = slot.d_in + chars_at;
+    args.q_len = slot.d_in; args.t_len = slot.d_in + m4;
+    args.q_off = reinterpret_cast<const uint32_t *>(slot.d_in + 2 * m4);
+    args.t_off = reinterpret_cast<const uint32_t *>(slot.d_in + 6 * m4);
+    args.t_counts = reinterpret_cast<const uint32_t *>(slot.d_in + 10 * m4);
+    args.pair_q = nullptr; args.pair_t = nullptr; args.out = slot.d_out;
+    args.q_stride = 0; args.t_stride = 0; args.n_q = m; args.n_t = m; args.n = m; args.q_first = 0; args.k = 0;
+    args.n_truth = in.n_truth; args.space_code = in.space_code;
+    const int status = launch_features(args, device, slot.stream);
+    if (status != DS_OK) return status;
+    const size_t out_bytes = static_cast<size_t>(m) * DS_FEATURES_COUNT * sizeof(float);
+    DS_HIP(hipMemcpyAsync(slot.h_out, slot.d_out, out_bytes, hipMemcpyDeviceToHost, slot.stream));
+    DS_HIP(hipStreamSynchronize(slot.stream));
+    std::memcpy(in.out + first * DS_FEATURES_COUNT, slot.h_out, out_bytes);
+    return DS_OK;
+}
+
+static int staged_features(const FeatureInputs &in, int device)
+{
+    FeatureStaging &staging = feature_staging();
+    std::lock_guard<std::mutex> guard(staging.mutex);
+    const int64_t chunks = (in.n + kStageChunk - 1) / kStageChunk;
+    const int workers = static_cast<int>(std::min<int64_t>(chunks, std::min(host_threads(), kStageMaxSlots)));
+    const int ensured = staging.ensure(device, workers);
+    if (ensured != DS_OK) return ensured;
+    std::atomic<int64_t> next{0};
+    std::atomic<int> failed{DS_OK};
+    auto work = [&](int worker) {
+        if (hipSetDevice(device) != hipSuccess) { failed.store(DS_E_HIP); return; }
+        for (;;) {
+            const int64_t chunk = next.fetch_add(1, std::memory_order_relaxed);
+            if (chunk >= chunks || failed.load(std::memory_order_relaxed) != DS_OK) break;
+            const int64_t first = chunk * kStageChunk;
+            const int status = stage_chunk(in, staging.slots[static_cast<size_t>(worker)], device, first,
+                                           std::min(kStageChunk, in.n - first));
+            if (status != DS_OK) { failed.store(status); break; }
+        }
+    };
+    if (workers <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < workers; ++t) pool.emplace_back(work, t);
+        for (std::thread &thread : pool) thread.join();
+    }
+    return failed.load();
+}
+
 static int launch_features(const FeatureArgs &args, int device, hipStream_t stream)
 {
     if (args.n == 0) return DS_OK;
@@ -621,6 +760,13 @@ static int launch_features(const FeatureArgs &args, int device, hipStream_t stre
 
 extern "C" {
 
+// The reference's own call (predict.py:216-219, feature_engineering.py:358-361) hands over HOST arrays in the padded layout
+// of encode_title: 255 + 255 + 60 + 2 bytes per pair, of which ~110 carry information.  The pairs are cut into chunks of
+// kStageChunk; a few host threads take chunks from a counter, each with a slot of its own (pinned staging buffers, device
+// buffers, a stream): pack the chunk's lengths, word counts and the titles' OWN bytes (row offsets instead of a stride)
+// into the pinned buffer, one asynchronous copy in, the kernel, one asynchronous copy out, a threaded memcpy into the
+// caller's `out`.  Chunks of different threads overlap on the GPU and on PCIe (H2D / kernel / D2H on separate streams).
+// The slots live as long as the process (hipHostMalloc is slow: paid by the first call).
 int ds_construct_features(const uint8_t *q_len, const uint8_t *t_len, const uint8_t *q_enc, const uint8_t *t_enc,
                           const uint32_t *t_word_counts, uint8_t space_code, uint32_t n_truth, int64_t n,
                           int64_t stride, int device, float *out)
@@ -634,25 +780,8 @@ int ds_construct_features(const uint8_t *q_len, const uint8_t *t_len, const uint
                    "ds_construct_features: length of pair %lld exceeds the row stride %lld", (long long)i,
                    (long long)stride);
     DS_HIP(hipSetDevice(device));
-    ds::DeviceBuffer<uint8_t> d_qlen, d_tlen, d_qenc, d_tenc;
-    ds::DeviceBuffer<uint32_t> d_counts;
-    ds::DeviceBuffer<float> d_out;
-    int status = d_qlen.upload(q_len, n);
-    if (status == DS_OK) status = d_tlen.upload(t_len, n);
-    if (status == DS_OK) status = d_qenc.upload(q_enc, static_cast<size_t>(n * stride));
-    if (status == DS_OK) status = d_tenc.upload(t_enc, static_cast<size_t>(n * stride));
-    if (status == DS_OK) status = d_counts.upload(t_word_counts, static_cast<size_t>(n) * DS_WORDS);
-    if (status == DS_OK) status = d_out.allocate(static_cast<size_t>(n) * DS_FEATURES_COUNT);
-    if (status != DS_OK) return status;
-    ds::FeatureArgs args{};
-    args.q_enc = d_qenc.ptr; args.q_len = d_qlen.ptr; args.t_enc = d_tenc.ptr; args.t_len = d_tlen.ptr;
-    args.t_counts = d_counts.ptr; args.pair_q = nullptr; args.pair_t = nullptr; args.out = d_out.ptr;
-    args.q_stride = stride; args.t_stride = stride; args.n_q = n; args.n_t = n; args.n = n; args.q_first = 0;
-    args.k = 0; args.n_truth = n_truth; args.space_code = space_code;
-    status = ds::launch_features(args, device, nullptr);
-    if (status != DS_OK) return status;
-    DS_HIP(hipMemcpy(out, d_out.ptr, d_out.bytes(), hipMemcpyDeviceToHost));
-    return DS_OK;
+    ds::FeatureInputs inputs{q_len, t_len, q_enc, t_enc, t_word_counts, space_code, n_truth, n, stride, out};
+    return ds::staged_features(inputs, device);
 }
 
 int ds_titles_create(const uint8_t *enc, int64_t stride, const uint8_t *len, const uint32_t *word_counts, int64_t n,
@@ -763,6 +892,16 @@ int ds_levenshtein_ratio_batch(const uint8_t *a_chars, const int64_t *a_off, con
     DS_HIP(hipGetLastError());
     DS_HIP(hipMemcpy(out, d_out.ptr, static_cast<size_t>(n), hipMemcpyDeviceToHost));
     return DS_OK;
+}
+
+int ds_levenshtein_ratio(const uint8_t *a, int la, const uint8_t *b, int lb)
+{
+    DS_REQUIRE(la >= 0 && lb >= 0 && (la == 0 || a) && (lb == 0 || b), "ds_levenshtein_ratio: bad arguments");
+    const int64_t a_off[2] = {0, la}, b_off[2] = {0, lb};
+    const uint8_t none = 0;
+    uint8_t ratio = 0;
+    const int status = ds_levenshtein_ratio_batch(la ? a : &none, a_off, lb ? b : &none, b_off, 1, 0, 0, &ratio);
+    return status != DS_OK ? status : static_cast<int>(ratio);
 }
 
 int ds_close_matches_device(ds_titles *queries, ds_titles *truth, const int32_t *d_pair_t, int64_t q_first, int32_t k,

@@ -229,6 +229,7 @@ class MatchMaker:
         self.truth_data = self.truth_data.loc[:, [COLUMN_TITLE_ID]]                         # :104
         self.index = TruthIndex(rowptr, truth_idx, idf32, self.sums_matrix_truth, device)
         self._rows = None
+        self._ids = None
 
         LOGGER.info(f'[{self.__class__.__name__}] Loaded pre-requisite data!')
 
@@ -288,6 +289,7 @@ class MatchMaker:
         self.truth_data = pd.DataFrame({COLUMN_TITLE_ID: ids})
         self.index = TruthIndex(arrays["rowptr"], arrays["truth_idx"], arrays["idf32"], arrays["sums32"], device)
         self._rows = None
+        self._ids = None
         return self
 
     @staticmethod
@@ -339,6 +341,21 @@ class MatchMaker:
             return self._rows
         return self._rows[np.asarray(row_numbers, dtype=np.int64)]
 
+    def _title_ids(self):
+        """title_id of every candidate of every row of `data`, [rows, top_n]: `self.truth_data.loc[top_matches, title_id]`
+        (:190) for the whole batch in ONE look-up.  The reference pays that `.loc` once per call of get_closest_matches
+        (270 us on a 500k-row frame: 27 s for 100k queries, against 16 ms for the kernels); here it is paid once."""
+        if self._ids is None:
+            rows = self.get_closest_matches_batch()
+            ids = self.truth_data[COLUMN_TITLE_ID]
+            index = self.truth_data.index
+            positional = (type(index).__name__ == "RangeIndex" and index.start == 0 and index.step == 1)   # common.py:60
+            if positional:
+                self._ids = ids.to_numpy()[rows]
+            else:   # any other index: `.loc` keeps its label semantics, still one call
+                self._ids = ids.loc[rows.reshape(-1)].to_numpy().reshape(rows.shape)
+        return self._ids
+
     def _get_top_n_matches(self, top_matches):
         """For the selected truth rows, gets the title_id's from self.truth_data (:183-190)."""
         if top_matches.shape[0] != self.top_n:
@@ -349,4 +366,7 @@ class MatchMaker:
         """
         Given the "row_number" of self.data, gets the closest (self.top_n) titles in self.truth_data
         """
-        return self._get_top_n_matches(self.get_closest_matches_batch()[row_number])
+        ids = self._title_ids()[row_number]
+        if ids.shape[0] != self.top_n:                                                        # :188-189
+            raise Exception('top_matches.shape[0] != self.top_n')
+        return ids.tolist()

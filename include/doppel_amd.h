@@ -114,7 +114,10 @@ int ds_jaccard_status(ds_index *index, void *stream, int32_t *status, int64_t Q)
 
 /* ---- Levenshtein / features:  fast_levenshtein_ratio + construct_features (feature_engineering.py:25-169) ------- */
 /* The 9-argument gufunc of feature_engineering.py:69-80 without the `dummy` argument: rows of q_enc / t_enc are
- * `stride` bytes apart (255 in predict.py:199-202), out = float32[n*66] written in place.  Host pointers. */
+ * `stride` bytes apart (255 in predict.py:199-202), out = float32[n*66] written in place.  Host pointers: the pairs
+ * travel in chunks of 16384 through pinned staging buffers (only the titles' own bytes, lengths and word counts are
+ * shipped, not the padding), up to 8 host threads with a stream each overlap copy-in / kernel / copy-out; the staging
+ * buffers (<= 110 MB pinned) are allocated by the first call and kept.  Calls are serialised by a mutex. */
 int ds_construct_features(const uint8_t *q_len, const uint8_t *t_len, const uint8_t *q_enc, const uint8_t *t_enc,
                           const uint32_t *t_word_counts, uint8_t space_code, uint32_t n_truth, int64_t n,
                           int64_t stride, int device, float *out);
@@ -138,6 +141,10 @@ int ds_construct_features_indexed_device(ds_titles *queries, ds_titles *truth, c
  * method 0 = bit-parallel LCS kernel (exact uint8-wrap DP where lengths require it), 1 = anti-diagonal DP kernel. */
 int ds_levenshtein_ratio_batch(const uint8_t *a_chars, const int64_t *a_off, const uint8_t *b_chars,
                                const int64_t *b_off, int64_t n, int method, int device, uint8_t *out);
+/* fast_levenshtein_ratio(a, b) (feature_engineering.py:25-63) for ONE pair of code strings on device 0, as SURVEY.md 8b
+ * lists it ("for tests"): returns the reference's uint8 result (0..255) or a negative DS_E_* code.  A one-pair wrapper
+ * over ds_levenshtein_ratio_batch (method 0): a kernel launch and two copies per call -- a test entry, not a hot path. */
+int ds_levenshtein_ratio(const uint8_t *a, int la, const uint8_t *b, int lb);
 
 /* ---- next row: Prediction._find_close_matches (predict.py:140-183) -------------------------------- */
 /* For query row q (q_first + q in the query table) and its k candidate truth rows pair_t[q*k .. q*k+k):
