@@ -265,25 +265,26 @@ def main():
         stop()
     else:
         import shutil
-        base = args.shared_dir or ("/dev/shm" if os.path.isdir("/dev/shm") else private_directory())
-        shared = os.path.join(base, f"ds_bench_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}")
+        import tempfile
+        failure = b""
         if rank == 0:
             stop = heartbeat("generating the workload")
-            shutil.rmtree(shared, ignore_errors=True)
-            failure = b""
             try:
+                # published inside a 0700 directory of this user (verified: a real directory, owned, not a planted link), in a
+                # fresh subdirectory whose name nobody can predict; its path travels through the rendezvous
+                base = private_directory(args.shared_dir or ("/dev/shm" if os.path.isdir("/dev/shm") else None))
+                shared = tempfile.mkdtemp(prefix=f"bench_{os.environ.get('MASTER_PORT', '0')}_", dir=base)
+                import atexit
+                atexit.register(shutil.rmtree, shared, True)
                 synth.publish_workload(synth.make_workload(truth, total_queries, seed=args.seed), shared)
             except Exception as error:  # noqa: BLE001 - every rank must learn about it
                 failure = f"{type(error).__name__}: {error}".encode()[:400]
             stop()
-            import atexit
-            atexit.register(shutil.rmtree, shared, True)
-        else:
-            failure = b""
-        failure = rendezvous.broadcast_bytes(failure if rank == 0 else None)
-        if failure:
-            log(f"rank {rank}: rank 0 could not generate the workload: {failure.decode()}")
+        published = rendezvous.broadcast_bytes((b"E" + failure if failure else b"P" + shared.encode()) if rank == 0 else None)
+        if published[:1] != b"P":
+            log(f"rank {rank}: rank 0 could not generate the workload: {published[1:].decode('utf-8', 'replace')}")
             sys.exit(4)
+        shared = published[1:].decode()
         workload = synth.load_workload(shared)
     if rank == 0:
         log(f"workload: {time.perf_counter() - t0:.1f}s  {synth.workload_statistics(workload)}")
@@ -371,6 +372,52 @@ def main():
         next_rows["forest_predict_ms"] = timer_c.elapsed_ms()
         next_rows["forest"] = "300 random trees, depth 6, 66 features"
 
+    # ---- the reference's own call surface on the same data (outside the timed region, one GPU): one get_closest_matches
+    # per row in a dict comprehension (predict.py:126-127), then ONE 9-argument construct_features over the pairs
+    # (predict.py:215-219) -- host arrays in, host arrays out, PCIe included.  The gathers that build the 9 arguments
+    # (predict.py:195-204) are the caller's and are not timed.  At most ~1M pairs (the padded arguments are 572 B per pair).
+    surface = None
+    if not distributed and os.environ.get("DS_BENCH_SURFACE", "1") != "0":
+        from doppel_speller_amd.distributed import slice_queries
+        n_surface = int(min(per_gpu, max(1, 1_000_000 // k)))
+        s_rowptr, s_cols, s_maxint = slice_queries(workload.q_rowptr, workload.q_cols, workload.q_maxint, q_begin,
+                                                   q_begin + n_surface)
+        match_maker = ds.MatchMaker.from_index(pipeline.index, s_rowptr, s_cols, s_maxint, workload.title_id, k)
+        t_a = time.perf_counter()
+        nearest = {row: match_maker.get_closest_matches(row) for row in range(n_surface)}
+        t_b = time.perf_counter()
+        surface_rows = match_maker.get_closest_matches_batch()
+        assert nearest[n_surface - 1] == workload.title_id[surface_rows[n_surface - 1]].tolist()
+        pair_q = q_begin + np.repeat(np.arange(n_surface), k)
+        pair_t = surface_rows.reshape(-1)
+        arguments = (np.ascontiguousarray(workload.q_len[pair_q]), np.ascontiguousarray(workload.t_len[pair_t]),
+                     np.ascontiguousarray(workload.q_enc[pair_q]), np.ascontiguousarray(workload.t_enc[pair_t]),
+                     np.ascontiguousarray(workload.t_counts[pair_t]))
+        surface_features = np.zeros((pair_q.shape[0], ds.FEATURES_COUNT), dtype=np.float32)
+        dummy = np.zeros(ds.FEATURES_COUNT, dtype=np.uint8)
+        feature_seconds = []
+        for _ in range(2):   # the first call allocates the pinned staging slots (kept for the process's life)
+            t_c = time.perf_counter()
+            ds.construct_features(*arguments, ds.SPACE_CODE, workload.n_truth, dummy, surface_features)
+            feature_seconds.append(time.perf_counter() - t_c)
+        n_pairs = int(pair_q.shape[0])
+        surface = {"queries": n_surface, "pairs": n_pairs,
+                   "get_closest_matches_loop_s": t_b - t_a,
+                   "get_closest_matches_us_per_call": 1e6 * (t_b - t_a) / n_surface,
+                   "construct_features_9arg_first_call_s": feature_seconds[0],
+                   "construct_features_9arg_s": feature_seconds[1],
+                   "pairs_per_s": n_pairs / ((t_b - t_a) + feature_seconds[1]),
+                   "pairs_per_s_first_call": n_pairs / ((t_b - t_a) + feature_seconds[0]),
+                   "host_bytes_per_pair": 572 + 264,
+                   "note": "host arrays in, host arrays out (PCIe and the host-side packing included): dict comprehension of "
+                           "get_closest_matches over the rows (first call = one batched launch through the host-pointer entry "
+                           "point + one title_id look-up for all rows) + one 9-argument construct_features over the pairs; "
+                           "the caller's gathers that build the 9 arguments are not timed"}
+        surface_check = surface_features
+        del arguments, nearest
+    else:
+        surface_check = None
+
     # ---- spot check against the oracle (outside the timed region)
     checked = 0
     cells_per_pair = None
@@ -390,6 +437,9 @@ def main():
                                               workload.t_enc[pair_t], workload.t_counts[pair_t], 1, workload.n_truth)
         assert np.array_equal(features.view(np.uint32), reference.view(np.uint32)), "features differ from the oracle"
         checked = n_check
+        if surface_check is not None:   # the surface's features are the pipeline's (same pairs, other entry point)
+            assert np.array_equal(surface_check[:n_check * k].view(np.uint32), reference.view(np.uint32)), \
+                "9-argument construct_features differs from the oracle"
         # reference DP cells per pair (SURVEY 8d `cells(q,t)`) on the verified pairs: the unit of the features stage
         cells_per_pair = float(np.mean(oracle.feature_cells(workload.q_len[pair_q], workload.t_len[pair_t],
                                                             workload.q_enc[pair_q], workload.t_enc[pair_t], 1)))
@@ -492,6 +542,8 @@ def main():
                 line["communicator_note"] = communicator_note
             line["collective"] = "ncclAllGather int32[queries_per_gpu, k] per step" if communicator.on_device else \
                 "host all-gather through the TCP rendezvous (rehearsal)"
+        if surface is not None:
+            line["surface"] = surface
         if next_rows:
             line["next_rows"] = next_rows
         if any(stats["phase_cycles"].values()):  # library built with -DDS_DIAGNOSTICS and DS_PHASE_TIMERS=1

@@ -154,7 +154,9 @@ int ds_problem_create(const uint8_t *truth_chars, const int64_t *truth_offsets, 
         for (int c = 0; c < n_gram; ++c) space.size *= static_cast<size_t>(space.symbols);
     }
     const size_t table = space.size;
-    // private tables: at most 1 GiB of them (a binary alphabet of 256 symbols has 2^24 tri-grams)
+    // private tables: 9 bytes per (worker, key) -- int64 counts / write positions + one presence byte -- capped at 2.25 GiB
+    // in all (a binary alphabet of 256 symbols has 2^24 tri-grams: 16 workers; the 37-symbol alphabet of transform_title
+    // has 50,653: every thread gets its tables)
     const int workers = static_cast<int>(std::max<size_t>(1, std::min<size_t>(static_cast<size_t>(threads),
                                                                               (size_t(1) << 28) / std::max<size_t>(table, 1))));
 

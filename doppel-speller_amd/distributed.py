@@ -59,11 +59,12 @@ def _receive(sock):
     return exactly(length)
 
 
-def private_directory():
-    """<tmp>/ds_<uid>: created 0700 and verified to be a real directory of this user (never a planted link)."""
+def private_directory(base=None):
+    """<base or tmp>/ds_<uid>: created 0700 and verified to be a real directory of this user that nobody else can write
+    to (never a planted link, never somebody else's directory)."""
     import stat
     import tempfile
-    path = os.path.join(tempfile.gettempdir(), f"ds_{os.getuid()}")
+    path = os.path.join(base or tempfile.gettempdir(), f"ds_{os.getuid()}")
     try:
         os.mkdir(path, 0o700)
     except FileExistsError:
@@ -71,6 +72,8 @@ def private_directory():
     info = os.lstat(path)
     if not stat.S_ISDIR(info.st_mode) or info.st_uid != os.getuid():
         raise _lib.DoppelError(f"{path} is not a directory owned by this user")
+    if info.st_mode & 0o077:
+        os.chmod(path, 0o700)
     return path
 
 

@@ -292,6 +292,22 @@ class MatchMaker:
         self._ids = None
         return self
 
+    @classmethod
+    def from_index(cls, index, q_rowptr, q_cols, q_maxint, title_ids, top_n):
+        """The call surface over a `TruthIndex` that is already resident (shared, not copied) and query rows that are
+        already built: what `bench.py`'s `surface` record and the tests time -- `get_closest_matches(row)` per row exactly
+        as predict.py:126-127 calls it."""
+        import pandas as pd
+        self = cls.__new__(cls)
+        self.top_n = top_n
+        self.number_of_truth_titles = index.n_truth
+        self._q_rowptr, self._q_cols, self._q_maxint = q_rowptr, q_cols, q_maxint
+        self.truth_data = pd.DataFrame({COLUMN_TITLE_ID: np.asarray(title_ids)})
+        self.index = index
+        self._rows = None
+        self._ids = None
+        return self
+
     @staticmethod
     def _count(column):  # common.py:145-147 get_n_grams_counter
         counter = {}

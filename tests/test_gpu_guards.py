@@ -59,9 +59,9 @@ sys.path.insert(0, %(root)r)
 sys.path.insert(0, %(tests)r)
 import doppel_speller_amd as ds
 from oracle import oracle
-from test_gpu_guards import second_posting_problem
+import test_gpu_guards
 oracle.build()
-rowptr, truth_idx, idf32, sums32, q_rowptr, q_cols, q_maxint, k = second_posting_problem()
+rowptr, truth_idx, idf32, sums32, q_rowptr, q_cols, q_maxint, k = getattr(test_gpu_guards, %(problem)r)()
 index = ds.TruthIndex(rowptr, truth_idx, idf32, sums32)
 rows = index.top_k(q_rowptr, q_cols, q_maxint, k)
 d_rowptr, d_cols, d_maxint = (ds._lib.DeviceArray.from_host(x) for x in (q_rowptr, q_cols, q_maxint))
@@ -73,7 +73,7 @@ print(json.dumps({"equal": bool(np.array_equal(rows, expected)), "device_equal":
                   "descending": bool((np.diff(rows.astype(np.int64), axis=1) < 0).all()),
                   "bounds_record": [int(x) for x in stats["bounds_record"]], "sparse_tiles": int(stats["sparse_tiles"]),
                   "dense_queries": int(stats["dense_queries"]), "error_queries": int(stats["error_queries"]),
-                  "library": ds._lib.library_path()}))
+                  "sparse_redos": int(stats["sparse_redos"]), "tiles": int(index.info()["tiles"]), "library": ds._lib.library_path()}))
 """
 
 
@@ -106,18 +106,72 @@ def second_posting_problem():
     return rowptr, truth_idx, idf32, sums32, q_rowptr, q_cols, q_maxint, 10
 
 
-def test_second_posting_of_a_taken_row_under_the_bounds_checking_build():
+def _under_the_bounds_checking_build(problem):
     from doppel_speller_amd import _lib
     variant = _lib.build_library(variant="boundscheck")      # built by __graft_entry__.build(); rebuilt here if stale
     env = dict(os.environ, DS_LIBRARY=variant)
-    script = _CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
+    script = _CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "problem": problem}
     result = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
     assert result.returncode == 0, result.stderr[-3000:]
     outcome = json.loads(result.stdout.strip().splitlines()[-1])
     assert outcome["library"] == variant
+    return outcome
+
+
+def test_second_posting_of_a_taken_row_under_the_bounds_checking_build():
+    outcome = _under_the_bounds_checking_build("second_posting_problem")
     assert outcome["bounds_record"] == [0, 0, 0], outcome           # no data-dependent global index left its array
     assert outcome["equal"] and outcome["device_equal"] and outcome["descending"], outcome
     assert outcome["sparse_tiles"] > 48 and outcome["dense_queries"] == 0 and outcome["error_queries"] == 0, outcome
+
+
+def descending_epochs_problem():
+    """13 narrow tiles (three or more list-pointer blocks for queries of 40 columns and up), rows of 3..100 columns: in the
+    internal sums32 order the long rows are the last tiles.  Three families of queries, top-100 (a weak cut: the sweeps run
+    far): 64..128 random columns -- they start in the LAST tiles and descend towards tile 0 with a pointer block (span 1..3)
+    SHORTER than an epoch of 4 tiles; 30..50 columns (span 4..7); 8..16 columns of a short row -- they start near tile 0 with a
+    span (15..31) LONGER than the tiles below the start.  The faults of 17:47 in round 3 lived in exactly these two corners
+    of `block_start = max(0, min(b, epoch_last - span + 1))` (profiles/r04_failure_causes.md (d))."""
+    rng = np.random.RandomState(1747)
+    n_rows, n_columns = 13 * NARROW_TILE, 3000
+    per_row = rng.randint(3, 101, n_rows)
+    rows = np.repeat(np.arange(n_rows, dtype=np.int64), per_row)
+    # column popularity: a few dense columns (signature bits, skipped under a threshold), a long flat tail
+    weights = 1.0 / (np.arange(n_columns) + 20.0)
+    cols = rng.choice(n_columns, rows.shape[0], p=weights / weights.sum())
+    pairs = np.unique(cols * n_rows + rows)                    # (column, row) ascending, duplicates within a row dropped
+    cols, rows = pairs // n_rows, pairs % n_rows
+    lengths = np.bincount(cols, minlength=n_columns)
+    rowptr = np.concatenate(([0], np.cumsum(lengths))).astype(np.int64)
+    truth_idx = rows.astype(np.int32)
+    idf64 = np.log(n_rows / np.maximum(lengths, 1))
+    idf32 = idf64.astype(np.float32)
+    sums32 = np.zeros(n_rows, dtype=np.float32)
+    for column in range(n_columns):                              # ascending column order, float32 adds
+        members = truth_idx[rowptr[column]:rowptr[column + 1]]
+        sums32[members] = sums32[members] + idf32[column]
+    by_row = np.argsort(rows, kind="stable")
+    row_start = np.concatenate(([0], np.cumsum(np.bincount(rows, minlength=n_rows))))
+    short_rows = np.nonzero(np.bincount(rows, minlength=n_rows) <= 16)[0]
+    query_columns = []
+    for _ in range(24):
+        query_columns.append(rng.choice(n_columns, rng.randint(64, 129), replace=False).tolist())
+    for _ in range(24):
+        query_columns.append(rng.choice(n_columns, rng.randint(30, 51), replace=False).tolist())
+    for _ in range(24):
+        row = short_rows[rng.randint(short_rows.shape[0])]
+        own = cols[by_row[row_start[row]:row_start[row + 1]]].tolist()
+        query_columns.append(sorted(set(own + rng.choice(n_columns, 6, replace=False).tolist())))
+    q_rowptr, q_cols, q_maxint = queries_of(query_columns, idf32, idf64)
+    return rowptr, truth_idx, idf32, sums32, q_rowptr, q_cols, q_maxint, 100
+
+
+def test_descending_epochs_pointer_blocks_under_the_bounds_checking_build():
+    outcome = _under_the_bounds_checking_build("descending_epochs_problem")
+    assert outcome["tiles"] == 13, outcome
+    assert outcome["bounds_record"] == [0, 0, 0], outcome           # list pointers, quads, rows: every index inside its array
+    assert outcome["equal"] and outcome["device_equal"] and outcome["descending"], outcome
+    assert outcome["sparse_tiles"] > 72 and outcome["error_queries"] == 0, outcome
 
 
 def _redo_problem(tied):
