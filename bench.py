@@ -139,8 +139,45 @@ def cpu_baseline(workload, k, budget_seconds):
             "cpu": cpu_model(), "host_threads": cores,
             "pilot_same_threads": {"pairs_per_s": round(sweep[best], 1), **pilots[best]},
             "thread_sweep_pairs_per_s": {str(t): round(v, 1) for t, v in sweep.items()},
+            "thread_counts_not_tried": [t for t in candidates if t not in sweep],   # the sweep stops when 60 % of the budget is spent
+            "thread_sweep_note": "ascending thread counts until 60 % of --cpu-seconds is spent; counts listed in "
+                                 "thread_counts_not_tried were NOT measured in this run (a longer --cpu-seconds measures them)",
             "thread_sweep_pilots": {str(t): v for t, v in pilots.items()},
             "queries_per_s": n_sample / tj, "feature_pairs_per_s": n_sample * k / tf}
+
+
+def recurrence_trip_counts(q_len, t_len, q_enc, t_enc, space=1):
+    """Text characters the features kernel's bit-parallel LCS recurrence steps through per pair (its dominant loop: one step =
+    one character of the text against the 32- or 64-bit column vector), by call site, on a sample of pairs -- the trip counts
+    that turn the static instruction counts of profiles/r04_features_isa_counts.txt into a dynamic picture.  Two pairs share a
+    wave, so a wave steps through the LONGER of its two pairs' loops: `per_wave_pair` is that maximum, averaged.
+    feature_engineering.py:106 lev(title, truth): text = the longer string; :128-149 word loop: per truth word (first 15),
+    ceil(|title without spaces| / 32) batches of min(|word|, |title without spaces|) steps; :161-162 lev(reconstructed,
+    truth): the reconstructed title is about as long as the truth title."""
+    lq, lt = np.asarray(q_len, dtype=np.int64), np.asarray(t_len, dtype=np.int64)
+    n = lq.shape[0]
+    columns = np.arange(q_enc.shape[1])
+    lw = ((np.asarray(q_enc) != space) & (columns[None, :] < lq[:, None])).sum(axis=1)
+    word_steps = np.zeros(n, dtype=np.int64)
+    short = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        text = np.asarray(t_enc[i, :lt[i]])
+        cuts = np.concatenate(([-1], np.nonzero(text == space)[0], [lt[i]]))
+        lengths = np.diff(cuts)[:15] - 1
+        lengths = lengths[lengths > 0]
+        if lw[i] > 0:
+            word_steps[i] = int((-(-lw[i] // 32) * np.minimum(lengths, lw[i])).sum())
+            short[i] = int((-(-lw[i] // 32) * np.minimum(lengths, lw[i]))[lengths <= 32].sum())
+    whole = np.maximum(lq, lt)
+    total = whole + word_steps + lt
+
+    def per_wave(values):
+        even = values[:n - n % 2].reshape(-1, 2).max(axis=1)
+        return float(even.mean()) if even.shape[0] else float(values.mean())
+    return {"title_vs_truth": float(whole.mean()), "word_loop": float(word_steps.mean()),
+            "reconstructed_vs_truth": float(lt.mean()), "total": float(total.mean()), "per_wave_pair": per_wave(total),
+            "share_on_the_32_bit_path": float((short.sum() + whole[np.minimum(lq, lt) <= 32].sum() +
+                                               lt[np.minimum(lq, lt) <= 32].sum()) / max(1, total.sum()))}
 
 
 def resolve_config(name, world, queries=None, truth=None, k=None):
@@ -420,7 +457,7 @@ def main():
 
     # ---- spot check against the oracle (outside the timed region)
     checked = 0
-    cells_per_pair = None
+    cells_per_pair = recurrence_steps = None
     if args.check > 0:
         from oracle import oracle
         n_check = min(args.check, per_gpu)
@@ -443,7 +480,17 @@ def main():
         # reference DP cells per pair (SURVEY 8d `cells(q,t)`) on the verified pairs: the unit of the features stage
         cells_per_pair = float(np.mean(oracle.feature_cells(workload.q_len[pair_q], workload.t_len[pair_t],
                                                             workload.q_enc[pair_q], workload.t_enc[pair_t], 1)))
+        recurrence_steps = recurrence_trip_counts(workload.q_len[pair_q], workload.t_len[pair_t], workload.q_enc[pair_q],
+                                                  workload.t_enc[pair_t])
 
+    host_rss, published_bytes = None, 0
+    if distributed:
+        import resource
+        import struct
+        mine = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20        # KiB -> GiB
+        host_rss = [round(struct.unpack("<d", raw)[0], 2) for raw in rendezvous.all_gather_bytes(struct.pack("<d", mine))]
+        if shared is not None and rank == 0:
+            published_bytes = sum(os.path.getsize(os.path.join(shared, name)) for name in os.listdir(shared))
     if rank == 0:
         pairs_per_step = total_queries * k
         ms_per_step = 1000.0 * elapsed / args.steps
@@ -470,6 +517,7 @@ def main():
                             "the reference algorithm's bandwidth floor, not an efficiency.  `traffic` = 2 * FETCH_SIZE + "
                             "WRITE_SIZE per launch from the entry of profiles/pmc_latest.json measured on this build "
                             "and workload (FETCH_SIZE counts half of coalesced streams on gfx950), else null"}
+        features_bound_model = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as handle:
@@ -479,6 +527,7 @@ def main():
                         entry.get("build_id") == build_id):   # stale entries are ignored
                     roofline["traffic"] = entry.get("hbm_bytes_per_launch")
                     roofline["bound_model"] = entry.get("bound_model")
+                    features_bound_model = entry.get("features_bound_model")
         # ds_construct_features_kernel: bound by VALU integer work, not HBM.  Ceiling of the REFERENCE's DP
         # formulation: 256 CUs x 128 lanes per clock (the f32 vector peak of the microarchitecture guide, 157.3 TF = 2 x
         # 256 x 128 x 2.4 GHz) / 5 integer operations per DP cell.  The kernel computes LCS bit-parallel (64 cells per 64-bit
@@ -492,6 +541,8 @@ def main():
             "frac": None if cells_rate is None else cells_rate / valu_cells_peak,
             "hbm_frac": feature_bytes / (mean_f * 1e-3) / 1e9 / HBM_PEAK_GBS, "hbm_bytes_per_pair": 330,
             "avg_launch_ms": mean_f, "reference_dp_cells_per_pair": cells_per_pair,
+            "recurrence_steps_per_pair": recurrence_steps,
+            "bound_model": features_bound_model,
             "note": "peak = 256 CUs x 128 integer lanes x 2.4 GHz / 5 operations per DP cell (SURVEY.md 8d); cells counted "
                     "by the oracle's feature_cells on the verified pairs"}
         line = {
@@ -537,6 +588,8 @@ def main():
             "build_id": build_id,
         }
         if distributed:
+            line["host_peak_rss_gib"] = host_rss          # every rank's peak resident set (the mapped workload's pages included)
+            line["published_workload_gib"] = published_bytes / 2 ** 30
             line["rccl_ranks"] = world if communicator.on_device else 0
             if communicator_note:
                 line["communicator_note"] = communicator_note

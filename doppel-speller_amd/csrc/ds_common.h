@@ -132,6 +132,8 @@ struct ds_index {
                                            // signature (bit g = row is in the posting list of the g-th densest column), word 4 =
                                            // sums32 bits, word 5 = duplicate rank (below), words 6..7 unused
     ds::DeviceBuffer<int8_t> sig_column;   // [n_columns] signature bit of a column, -1 for all but the 128 densest
+    ds::DeviceBuffer<int64_t> row_start;   // [n_truth + 1] forward index: row t's columns are row_cols[row_start[t] .. row_start[t + 1])
+    ds::DeviceBuffer<int32_t> row_cols;    // [nnz] ascending column ids per row, rows in internal order (the exact stage's input)
     // duplicate rank of a row (word 5 of its record): rows with the same column set and sums32 bits but a larger index (saturating)
     bool rows_sorted = false;              // internal row order ascends with sums32 (ds_index_create, DS_SORT_ROWS != 0)
     bool literal_only = false;             // idf32 / sums32 hold negative or non-finite values: the bounds of the fast kernel

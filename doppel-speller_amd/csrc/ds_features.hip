@@ -92,22 +92,9 @@ __device__ __forceinline__ int lcs_bitparallel(const WaveScratch &w, const uint8
     return __popcll(~v & valid);
 }
 
-// The same recurrence for a pattern of at most 32 characters (most titles, nearly every word): carries only travel upwards,
-// so the low 32 bits of the 64-bit column vector are a recurrence of their own -- half the vector instructions (the kernel is
-// bound by their issue) and a 4-byte LDS read per step.  v & ~match == v ^ (v & match).
-__device__ __forceinline__ int lcs_bitparallel32(const WaveScratch &w, const uint8_t *text, int n, int m)
-{
-    const uint32_t *low = reinterpret_cast<const uint32_t *>(w.masks);  // little endian: word 2c = bits 0..31 of masks[c]
-    uint32_t v = ~0u;
-#pragma unroll 4
-    for (int i = 0; i < n; ++i) {
-        const uint32_t u = v & low[2 * text[i]];
-        v = (v + u) | (v ^ u);
-    }
-    const uint32_t valid = m >= 32 ? ~0u : ((1u << m) - 1u);
-    return __popc(~v & valid);
-}
-
+// (Round 4 tried a 32-bit recurrence for patterns of at most 32 characters -- 95 % of the steps; 5-8 instead of 9-10 vector
+// instructions per step in the ISA: the kernel got 17 % SLOWER, 1.70 -> 2.00 ms per 1M pairs, profiles/r04_tuning.txt.  The
+// steps are not what binds it: a second code path per call site and 4-byte reads at an 8-byte stride cost more.)
 // Literal fast_levenshtein_ratio (:25-63) with uint8 wrap-around, cooperative over the wave; a/b in LDS.
 __device__ uint8_t levenshtein_literal(WaveScratch &w, const uint8_t *a, int la, const uint8_t *b, int lb, int lane)
 {
@@ -238,8 +225,7 @@ __device__ uint8_t levenshtein_g(WaveScratch &w, const uint8_t *a, int la, const
         const uint8_t *pattern = la <= lb ? a : b;
         const uint8_t *text = la <= lb ? b : a;
         build_masks_g(w, pattern, shorter, gl);
-        const int lcs = shorter <= 32 ? lcs_bitparallel32(w, text, la + lb - shorter, shorter)
-                                      : lcs_bitparallel(w, text, la + lb - shorter, shorter);
+        const int lcs = lcs_bitparallel(w, text, la + lb - shorter, shorter);
         return ratio_from_lcs(lcs, la + lb);
     }
     return levenshtein_literal_g(w, a, la, b, lb, gl);
@@ -347,8 +333,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(
                     if (fast) {
                         if (start < lw) {
                             const int window = min(length, lw - start);                      // :142
-                            const int lcs = length <= 32 ? lcs_bitparallel32(w, w.qw + start, window, length)
-                                                         : lcs_bitparallel(w, w.qw + start, window, length);
+                            const int lcs = lcs_bitparallel(w, w.qw + start, window, length);
                             ratio = ratio_table[(window + length) * kRatioLcs + lcs];         // :146
                         }
                     } else {

@@ -200,6 +200,11 @@ struct IndexImage {
     std::vector<float> tile_sums_min, tile_sums_max;
     std::vector<float> sums;      // sums32 in internal row order (what the kernels index)
     std::vector<int8_t> sig_column;
+    // forward index (round 4): the columns of every row, ascending, rows in internal order -- row t's are
+    // row_cols[row_start[t] .. row_start[t + 1]).  The exact stage of the fast kernel reads a candidate's ~21 columns in one
+    // go instead of searching the row in every query column's posting list.
+    std::vector<int64_t> row_start;
+    std::vector<int32_t> row_cols;
 };
 
 int64_t choose_tile_rows(int64_t N)
@@ -474,6 +479,22 @@ int build_index_image(const int64_t *rowptr, const int32_t *truth_idx, const flo
             record[6] = static_cast<uint32_t>(original[static_cast<size_t>(t)]);  // the caller's row index: what the kernels return
         }
     });
+    // forward index: per row range (threaded), columns ascending -- the walk visits the columns in ascending order
+    std::vector<int64_t> row_start(static_cast<size_t>(N) + 1, 0);
+    ds::for_postings_by_row_range(rowptr, truth_idx, V, N, threads, [&](int, int64_t, int64_t from, int64_t to) {
+        for (int64_t p = from; p < to; ++p) ++row_start[static_cast<size_t>(truth_idx[p]) + 1];
+    });
+    for (int64_t t = 0; t < N; ++t) row_start[static_cast<size_t>(t) + 1] += row_start[static_cast<size_t>(t)];
+    std::vector<int32_t> row_cols(static_cast<size_t>(nnz));
+    {
+        std::vector<int64_t> fill(row_start.begin(), row_start.end() - 1);
+        ds::for_postings_by_row_range(rowptr, truth_idx, V, N, threads, [&](int, int64_t g, int64_t from, int64_t to) {
+            for (int64_t p = from; p < to; ++p) row_cols[static_cast<size_t>(fill[static_cast<size_t>(truth_idx[p])]++)] = static_cast<int32_t>(g);
+        });
+    }
+    phase("forward index");
+    image.row_start.swap(row_start);
+    image.row_cols.swap(row_cols);
     image.n_tiles = n_tiles;
     image.tile_rows = tile_rows;
     image.nnz = nnz;
@@ -545,6 +566,9 @@ int ds_index_create(const int64_t *rowptr, const int32_t *truth_idx, const float
     if (status == DS_OK) status = index->tile_sums_max.upload(image.tile_sums_max.data(), image.tile_sums_max.size());
     if (status == DS_OK) status = index->signature.upload(records.data(), records.size());
     if (status == DS_OK) status = index->sig_column.upload(sig_column.data(), sig_column.size());
+    if (status == DS_OK) status = index->row_start.upload(image.row_start.data(), image.row_start.size());
+    if (status == DS_OK) status = index->row_cols.upload(image.row_cols.data(), image.row_cols.size());
+    if (status == DS_OK && image.row_cols.empty()) status = index->row_cols.allocate(1);
     if (status == DS_OK) status = index->control.allocate(ds::kControlWords);
     if (status == DS_OK && (hipStreamCreate(&index->stream) != hipSuccess ||
                             hipEventCreate(&index->event_begin) != hipSuccess ||
@@ -586,7 +610,8 @@ int ds_index_image_digest(const int64_t *rowptr, const int32_t *truth_idx, const
     digest[3] = fnv(image.records.data(), image.records.size() * 4);
     digest[4] = fnv(image.tile_sums_min.data(), image.tile_sums_min.size() * 4) ^ fnv(image.tile_sums_max.data(), image.tile_sums_max.size() * 4) ^
                 fnv(image.sums.data(), image.sums.size() * 4);
-    digest[5] = fnv(image.sig_column.data(), image.sig_column.size());
+    digest[5] = fnv(image.sig_column.data(), image.sig_column.size()) ^ fnv(image.row_start.data(), image.row_start.size() * 8) ^
+                fnv(image.row_cols.data(), image.row_cols.size() * 4);
     digest[6] = image.quads;
     digest[7] = image.literal_only ? 1u : 0u;
     return DS_OK;
@@ -626,7 +651,8 @@ int ds_index_info(const ds_index *index, int64_t info[8])
     info[3] = index->tile_rows;
     info[4] = index->n_tiles;
     info[5] = static_cast<int64_t>(index->col_ptr.bytes() + index->postings.bytes() + index->posting_sums.bytes() + index->idf32.bytes() +
-                                   index->sums32.bytes() + index->signature.bytes() + index->sig_column.bytes());
+                                   index->sums32.bytes() + index->signature.bytes() + index->sig_column.bytes() +
+                                   index->row_start.bytes() + index->row_cols.bytes());
     info[6] = index->n_quads * 4;
     info[7] = 0;
     return DS_OK;

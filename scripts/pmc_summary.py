@@ -79,6 +79,36 @@ def main():
         "source": f"profiles/{tag}_pmc_summary.txt; issue costs and the FETCH_SIZE factor from profiles/r02_calibration.txt",
     }
     print(json.dumps(model, indent=1))
+    # ---- ds_construct_features_kernel: the same model (4 workgroups of 4 waves per CU = 4 waves per SIMD, like the calibration)
+    features_model = None
+    features_kernel = next((name for name in per if "ds_construct_features_kernel" in name), None)
+    if features_kernel is not None and durations[features_kernel]:
+        f = per[features_kernel]
+        tf = sum(durations[features_kernel]) / len(durations[features_kernel]) / 1e9
+        f_clock = f["SQ_BUSY_CYCLES"] / 32 / tf
+        f_valu = f["SQ_INSTS_VALU"] * VALU_CYCLES / SIMDS / f_clock
+        f_salu = f["SQ_INSTS_SALU"] * SALU_CYCLES_PER_SIMD / SIMDS / f_clock
+        f_issue = f_valu + PAIR_OVERLAP * f_salu
+        f_lds = f["SQ_LDS_IDX_ACTIVE"] / CUS / f_clock
+        f_hbm = (2.0 * f["FETCH_SIZE"] * 1024 + f["WRITE_SIZE"] * 1024) / HBM_PEAK
+        pairs = queries * k
+        features_model = {
+            "kernel_ms_under_pmc": tf * 1e3, "clock_ghz": f_clock / 1e9, "pairs": pairs,
+            "valu_issue_ms": f_valu * 1e3, "salu_issue_ms": f_salu * 1e3, "issue_ms": f_issue * 1e3,
+            "lds_busy_ms": f_lds * 1e3, "hbm_ms_at_8TBs": f_hbm * 1e3,
+            "frac_issue": f_issue / tf, "frac_lds": f_lds / tf, "frac_hbm": f_hbm / tf,
+            "binding": max((("instruction issue (VALU + SALU)", f_issue), ("LDS", f_lds), ("HBM", f_hbm)), key=lambda x: x[1])[0],
+            "frac": max(f_issue, f_lds, f_hbm) / tf,
+            "wait_share_of_wave_cycles": f["SQ_WAIT_ANY"] / f["SQ_WAVE_CYCLES"],
+            "lds_bank_conflict_share": f["SQ_LDS_BANK_CONFLICT"] / f["SQ_LDS_IDX_ACTIVE"],
+            "wave_instructions_per_pair": {name[len("SQ_INSTS_"):]: f[name] / pairs
+                                           for name in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD")},
+            "where_the_vector_instructions_go": "profiles/r04_features_isa_counts.txt x the trip counts of the bench line "
+                                                "(roofline_features.recurrence_steps_per_pair): the bit-parallel recurrence "
+                                                "(5-10 VALU per text character) and the staging around it",
+            "source": f"profiles/{tag}_pmc_summary.txt; issue costs from profiles/r02_calibration.txt (4 waves per SIMD)",
+        }
+        print("ds_construct_features_kernel:", json.dumps(features_model, indent=1))
     if "--write" in sys.argv:
         sys.path.insert(0, root)
         from doppel_speller_amd import _lib
@@ -89,7 +119,7 @@ def main():
                "WRITE_SIZE_KiB_per_launch": c["WRITE_SIZE"], "hbm_bytes_per_launch": hbm_bytes,
                "note": "hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes): FETCH_SIZE counts half the bytes of "
                        "coalesced 4/8/16-byte-per-lane streams on gfx950 (profiles/r02_calibration.txt)",
-               "bound_model": model}
+               "bound_model": model, "features_bound_model": features_model}
         path = os.path.join(root, "profiles", "pmc_latest.json")
         entries = []
         if os.path.exists(path):

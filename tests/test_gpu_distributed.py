@@ -129,7 +129,40 @@ def test_strong_scaling_rehearsal_two_ranks_share_one_published_workload(config,
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["queries"] == 20001
     assert line["config"]["queries_per_gpu"] == 10000 and line["config"]["k"] == k and line["verified_queries"] == 16
     assert line["roofline"]["geometry"] == "narrow" and line["value"] > 0     # 5M rows: narrow tiles (wide above 10M)
-    assert not [name for name in os.listdir("/dev/shm") if name.startswith("ds_bench_")]     # rank 0 cleaned up
+    _assert_nothing_published_is_left()
+
+
+def _assert_nothing_published_is_left():
+    """rank 0 published under <shm>/ds_<uid>/bench_<port>_<random>/ (a 0700 directory of this user) and removed it."""
+    private = os.path.join("/dev/shm", f"ds_{os.getuid()}")
+    assert not os.path.isdir(private) or not [name for name in os.listdir(private) if name.startswith("bench_")]
+    assert not [name for name in os.listdir("/dev/shm") if name.startswith("ds_bench_")]
+
+
+def test_c5_rehearsal_two_ranks_at_the_real_50m_truth_rows():
+    """the first 8-rank C5 run must not be the first time that concurrent 50M-row index builds share a host.
+    Two rank processes on the box's one GPU (DS_BENCH_SAME_DEVICE=1): rank 0 generates and publishes the REAL 50M-row truth
+    side once, both ranks map it, each builds its own replicated index (`cores / 2` host threads each, 2 x 20 GB on the
+    device) and answers its uneven shard of 20,001 queries at top-100 + features.  Asserted: wall clock under 300 s, the
+    answers verified, every rank's peak host RSS on the line (DESIGN.md section 7 states what to expect per rank)."""
+    import time
+    env = dict(os.environ, DS_BENCH_SAME_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    started = time.perf_counter()
+    result = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C5", "--queries",
+                             "20001", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--check", "8",
+                             "--host-communicator"], env=env, capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - started
+    assert result.returncode == 0, result.stderr[-3000:]
+    line = json.loads(result.stdout.strip().splitlines()[-1])
+    print(f"C5 two-rank rehearsal at 50M rows: wall {wall:.0f} s, peak host RSS per rank {line['host_peak_rss_gib']} GiB, "
+          f"published workload {line['published_workload_gib']:.1f} GiB")
+    assert wall < 300.0, wall
+    assert line["n_gpus"] == 2 and line["config"]["truth_titles"] == 50_000_000 and line["config"]["k"] == 100
+    assert line["config"]["queries_per_gpu"] == 10000 and line["verified_queries"] == 8
+    assert line["roofline"]["geometry"] == "wide" and len(line["host_peak_rss_gib"]) == 2
+    assert max(line["host_peak_rss_gib"]) < 120.0, line["host_peak_rss_gib"]
+    _assert_nothing_published_is_left()
 
 
 def test_row_gather_pads_and_compacts_uneven_shards_on_the_device():
