@@ -213,9 +213,15 @@ def test_candidate_overflow_inside_an_epoch_is_redone_and_counted(oracle, tied, 
     expected = oracle.jaccard_topk(rowptr, truth_idx, idf32, sums32, q_rowptr, q_cols, q_maxint, k)
     assert np.array_equal(rows, expected)
     assert stats["error_queries"] == 0
+    print("tied" if tied else "distinct", "sparse_redos", stats["sparse_redos"], stats["dense_reasons"])
     if tied:     # no threshold and no admission floor separates a thousand equal rows: the literal kernel answers
         assert stats["sparse_redos"] >= 1 and stats["dense_queries"] == 1
         assert stats["dense_reasons"]["overflow_sparse"] + stats["dense_reasons"]["ties"] == 1
+        if stats["dense_reasons"]["overflow_sparse"] == 1:
+            # the give-up bound itself (`++sparse_retries > 5`): five redos are counted, the sixth overflow hands the query over
+            assert stats["sparse_redos"] == 5, stats["sparse_redos"]
+        else:   # the admission floor's check ended it first ("ties": the k best themselves tie at the pivot): fewer redos
+            assert stats["sparse_redos"] <= 5, stats["sparse_redos"]
     else:        # the epoch is repeated under the tightened threshold and the admission floor, and fits
         assert 1 <= stats["sparse_redos"] <= 3 and stats["dense_queries"] == 0
 
