@@ -46,7 +46,7 @@ struct FeatureArgs {
     uint8_t space_code;
 };
 
-struct WaveScratch {
+struct PairScratch {           // what the features kernel needs per pair (2,848 B)
     unsigned long long masks[64];
     uint8_t q[256];
     uint8_t t[256];
@@ -56,6 +56,8 @@ struct WaveScratch {
     float features[72];
     int32_t word_begin[16];
     int32_t word_len[16];
+};
+struct WaveScratch : PairScratch {
     uint8_t token_begin[128];  // token-sort scratch of the close-match kernel
     uint8_t token_len[128];
 };
@@ -79,7 +81,7 @@ __device__ __forceinline__ void build_masks(WaveScratch &w, const uint8_t *patte
 }
 
 // LCS length of text[0..n) against the pattern whose masks are in scratch.masks (pattern length m <= 64).
-__device__ __forceinline__ int lcs_bitparallel(const WaveScratch &w, const uint8_t *text, int n, int m)
+__device__ __forceinline__ int lcs_bitparallel(const PairScratch &w, const uint8_t *text, int n, int m)
 {
     unsigned long long v = ~0ull;
 #pragma unroll 4
@@ -158,25 +160,37 @@ __device__ uint8_t levenshtein_wave(WaveScratch &w, const uint8_t *a, int la, co
 // whole-title comparisons) or uses ~20 of them (one window start per lane).  Two pairs share a wavefront: every
 // instruction now serves two pairs.  Lanes 0-31 work on one pair, lanes 32-63 on another, each with its own scratch;
 // control flow may diverge between the halves (different word counts and lengths), never inside one.
-constexpr int kGroup = 32;
+#ifndef DS_FEAT_GROUP
+#define DS_FEAT_GROUP 32   // lanes per pair: 32 (two pairs per wave) or 16 (four)
+#endif
+#ifndef DS_FEAT_WAVES
+#define DS_FEAT_WAVES 4    // waves per workgroup of ds_construct_features_kernel
+#endif
+constexpr int kGroup = DS_FEAT_GROUP, kPairsPerWave = 64 / kGroup, kFeatKernelWaves = DS_FEAT_WAVES;
+static_assert((kGroup == 16 || kGroup == 32) && kGroup > DS_WORDS, "a pair's lanes: one per truth word at least");
 
-// the ballot bits of this lane's half
+// the ballot bits of this lane's group
 __device__ __forceinline__ uint32_t group_ballot(bool predicate, int group)
 {
-    return static_cast<uint32_t>(__ballot(predicate) >> (group * kGroup));
+    if constexpr (kGroup == 32) return static_cast<uint32_t>(__ballot(predicate) >> (group * kGroup));
+    return static_cast<uint32_t>(__ballot(predicate) >> (group * kGroup)) & ((1u << (kGroup & 31)) - 1u);
 }
 
-__device__ __forceinline__ void build_masks_g(WaveScratch &w, const uint8_t *pattern, int m, int gl)
+__device__ __forceinline__ void build_masks_g(PairScratch &w, const uint8_t *pattern, int m, int gl)
 {
     w.masks[gl] = 0ull;
     w.masks[gl + kGroup] = 0ull;
+    if constexpr (kGroup == 16) {
+        w.masks[gl + 32] = 0ull;
+        w.masks[gl + 48] = 0ull;
+    }
     wave_sync();
     for (int j = gl; j < m; j += kGroup) atomicOr(&w.masks[pattern[j]], 1ull << j);
     wave_sync();
 }
 
 // levenshtein_literal with 32 cooperating lanes
-__device__ uint8_t levenshtein_literal_g(WaveScratch &w, const uint8_t *a, int la, const uint8_t *b, int lb, int gl)
+__device__ uint8_t levenshtein_literal_g(PairScratch &w, const uint8_t *a, int la, const uint8_t *b, int lb, int gl)
 {
     const int total_length = la + lb;
     if (la > lb) {  // :35-37
@@ -217,7 +231,7 @@ __device__ __forceinline__ bool codes_below_64_g(const uint8_t *s, int n, int gl
     return group_ballot(!ok, group) == 0u;
 }
 
-__device__ uint8_t levenshtein_g(WaveScratch &w, const uint8_t *a, int la, const uint8_t *b, int lb, int gl,
+__device__ uint8_t levenshtein_g(PairScratch &w, const uint8_t *a, int la, const uint8_t *b, int lb, int gl,
                                  bool small_alphabet)
 {
     const int shorter = la < lb ? la : lb;
@@ -234,31 +248,35 @@ __device__ uint8_t levenshtein_g(WaveScratch &w, const uint8_t *a, int la, const
 // ratio_from_lcs for every (total length <= 128, LCS <= 64): what the word loop needs (window <= word <= 64 chars)
 constexpr int kRatioLengths = 129, kRatioLcs = 65;
 
-__global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(FeatureArgs a)
+__global__ __launch_bounds__(kFeatKernelWaves * 64) void ds_construct_features_kernel(FeatureArgs a)
 {
-    __shared__ WaveScratch scratch[kFeatWaves * 2];
+    __shared__ PairScratch scratch[kFeatKernelWaves * kPairsPerWave];
     // the float64 evaluation of :63 costs ~35 instructions per window; a workgroup tabulates it once
     __shared__ uint8_t ratio_table[kRatioLengths * kRatioLcs];
-    for (int i = threadIdx.x; i < kRatioLengths * kRatioLcs; i += kFeatWaves * 64)
+    for (int i = threadIdx.x; i < kRatioLengths * kRatioLcs; i += kFeatKernelWaves * 64)
         ratio_table[i] = ratio_from_lcs(i % kRatioLcs, i / kRatioLcs);
     __syncthreads();
-    const int lane = threadIdx.x & 63, group = lane >> 5, gl = lane & (kGroup - 1);
-    WaveScratch &w = scratch[(threadIdx.x >> 6) * 2 + group];
-    const int64_t wave_global = static_cast<int64_t>(blockIdx.x) * kFeatWaves + (threadIdx.x >> 6);
-    const int64_t wave_count = static_cast<int64_t>(gridDim.x) * kFeatWaves;
+    const int lane = threadIdx.x & 63, group = kGroup == 32 ? lane >> 5 : lane >> 4, gl = lane & (kGroup - 1);
+    PairScratch &w = scratch[(threadIdx.x >> 6) * kPairsPerWave + group];
+    const int64_t wave_global = static_cast<int64_t>(blockIdx.x) * kFeatKernelWaves + (threadIdx.x >> 6);
+    const int64_t wave_count = static_cast<int64_t>(gridDim.x) * kFeatKernelWaves;
     const uint8_t space = a.space_code;
     const float nan = __uint_as_float(0x7fc00000u);
 
-    for (int64_t first_pair = wave_global * 2; first_pair < a.n; first_pair += wave_count * 2) {
+    for (int64_t first_pair = wave_global * kPairsPerWave; first_pair < a.n; first_pair += wave_count * kPairsPerWave) {
         const int64_t pair = first_pair + group;
         if (pair >= a.n) continue;  // the odd last pair: the upper half idles (no wave-wide collective below needs it)
         float *out = a.out + pair * DS_FEATURES_COUNT;
         const int64_t qi = a.pair_q ? a.pair_q[pair] : (a.k > 0 ? a.q_first + pair / a.k : pair);
         const int64_t ti = a.pair_t ? a.pair_t[pair] : pair;
         if (qi < 0 || qi >= a.n_q || ti < 0 || ti >= a.n_t) {  // e.g. a -1 row of a failed top-k
-            out[gl] = nan;
-            out[kGroup + gl] = nan;
-            if (gl < 2) out[64 + gl] = nan;
+            if constexpr (kGroup == 32) {
+                out[gl] = nan;
+                out[kGroup + gl] = nan;
+                if (gl < 2) out[64 + gl] = nan;
+            } else {
+                for (int i = gl; i < DS_FEATURES_COUNT; i += kGroup) out[i] = nan;
+            }
             continue;
         }
         const int lq = a.q_len[qi], lt = a.t_len[ti];                                      // :101-102
@@ -407,9 +425,15 @@ __global__ __launch_bounds__(kFeatWaves * 64) void ds_construct_features_kernel(
             w.features[5] = static_cast<float>(recon_ratio);
         }
         wave_sync();
-        out[gl] = w.features[gl];
-        out[kGroup + gl] = w.features[kGroup + gl];
-        if (gl < 2) out[64 + gl] = w.features[64 + gl];
+        if constexpr (kGroup == 32) {
+            out[gl] = w.features[gl];
+            out[kGroup + gl] = w.features[kGroup + gl];
+            if (gl < 2) out[64 + gl] = w.features[64 + gl];
+        } else {
+#pragma unroll
+            for (int i = 0; i < DS_FEATURES_COUNT; i += kGroup)
+                if (i + gl < DS_FEATURES_COUNT) out[i + gl] = w.features[i + gl];
+        }
     }
 }
 
@@ -752,9 +776,10 @@ static int launch_features(const FeatureArgs &args, int device, hipStream_t stre
 {
     if (args.n == 0) return DS_OK;
     (void)device;
-    const int64_t blocks_needed = (args.n + 2 * kFeatWaves - 1) / (2 * kFeatWaves);
+    const int64_t pairs_per_block = kPairsPerWave * kFeatKernelWaves;
+    const int64_t blocks_needed = (args.n + pairs_per_block - 1) / pairs_per_block;
     const int grid = static_cast<int>(std::min<int64_t>(blocks_needed, 256 * 32));
-    hipLaunchKernelGGL(ds_construct_features_kernel, dim3(grid), dim3(kFeatWaves * 64), 0, stream, args);
+    hipLaunchKernelGGL(ds_construct_features_kernel, dim3(grid), dim3(kFeatKernelWaves * 64), 0, stream, args);
     DS_HIP(hipGetLastError());
     return DS_OK;
 }
