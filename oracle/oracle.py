@@ -25,7 +25,11 @@ def build(force=False):
     source = os.path.join(_HERE, "doppel_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(source):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libdoppel_oracle.so"])
+    subprocess.check_call(["make", "-C", _HERE, "-s", "libdoppel_cpu.so"])   # the oracle behind the product's C ABI (make: up to date or rebuilt)
     return _LIB_PATH
+
+
+CPU_ABI_PATH = os.path.join(_HERE, "libdoppel_cpu.so")
 
 
 def _ptr(array, ctype):
