@@ -69,6 +69,26 @@ def test_nine_argument_construct_features_through_the_staged_path(oracle):
     assert np.array_equal(view.view(np.uint32), features[:1000].view(np.uint32)) and not wide[:, ds.FEATURES_COUNT:].any()
 
 
+def test_staged_path_at_the_largest_titles_the_encoding_allows(oracle):
+    """Every pair 255 + 255 characters (the uint8 length's limit, settings.py:67-68): a chunk's packed bytes fill its pinned
+    staging buffer to the last byte (16,384 pairs x 580 B), the DP matrices wrap (L = 510 > 255: literal path), two chunks."""
+    import doppel_speller_amd as ds
+    rng = np.random.RandomState(255)
+    n = 16384 + 37
+    q_enc = rng.randint(1, 38, (n, 255)).astype(np.uint8)   # spaces (code 1) wherever they fall
+    t_enc = rng.randint(2, 38, (n, 255)).astype(np.uint8)
+    t_enc[:, ::9] = 1                                   # 29 spaces: 30 words per truth title (the first one empty), 15 of them count
+    lengths = np.full(n, 255, dtype=np.uint8)
+    counts = rng.randint(1, 5000, (n, 15)).astype(np.uint32)
+    features = np.zeros((n, ds.FEATURES_COUNT), dtype=np.float32)
+    ds.construct_features(lengths, lengths, q_enc, t_enc, counts, ds.SPACE_CODE, 500000, np.zeros(66, np.uint8), features)
+    sample = np.concatenate((np.arange(8), [16383, 16384, n - 1]))     # both sides of the chunk boundary
+    expected = oracle.construct_features(lengths[sample], lengths[sample], q_enc[sample], t_enc[sample], counts[sample],
+                                         ds.SPACE_CODE, 500000)
+    assert np.array_equal(features[sample].view(np.uint32), expected.view(np.uint32))
+    assert np.isfinite(features[:, :6]).all() and (features[:, 0] == 255).all() and (features[:, 3] == 30).all()
+
+
 def test_single_pair_levenshtein_entry(oracle, golden_kat):
     """`ds_levenshtein_ratio(a, la, b, lb)` as SURVEY.md 8b lists it: the reference's uint8 for one pair."""
     import ctypes
