@@ -667,15 +667,23 @@ struct FeatureStaging {
         if (device != wanted_device) release();
         device = wanted_device;
         while (static_cast<int>(slots.size()) < wanted_slots) {
-            FeatureSlot slot;
-            DS_HIP(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
-            slots.push_back(slot);   // registered first: release() frees whatever of it got allocated
-            FeatureSlot &mine = slots.back();
-            DS_HIP(hipHostMalloc(reinterpret_cast<void **>(&mine.h_in), kStageInBytes, hipHostMallocDefault));
-            DS_HIP(hipHostMalloc(reinterpret_cast<void **>(&mine.h_out), kStageChunk * DS_FEATURES_COUNT * sizeof(float), hipHostMallocDefault));
-            DS_HIP(hipMalloc(reinterpret_cast<void **>(&mine.d_in), kStageInBytes));
-            DS_HIP(hipMalloc(reinterpret_cast<void **>(&mine.d_out), kStageChunk * DS_FEATURES_COUNT * sizeof(float)));
+            const int added = add_slot();
+            if (added != DS_OK) {   // a half-built slot must never be handed out by a later call: start over next time
+                release();
+                return added;
+            }
         }
+        return DS_OK;
+    }
+    int add_slot()
+    {
+        slots.emplace_back();   // registered first: release() frees whatever of it got allocated
+        FeatureSlot &mine = slots.back();
+        DS_HIP(hipStreamCreateWithFlags(&mine.stream, hipStreamNonBlocking));
+        DS_HIP(hipHostMalloc(reinterpret_cast<void **>(&mine.h_in), kStageInBytes, hipHostMallocDefault));
+        DS_HIP(hipHostMalloc(reinterpret_cast<void **>(&mine.h_out), kStageChunk * DS_FEATURES_COUNT * sizeof(float), hipHostMallocDefault));
+        DS_HIP(hipMalloc(reinterpret_cast<void **>(&mine.d_in), kStageInBytes));
+        DS_HIP(hipMalloc(reinterpret_cast<void **>(&mine.d_out), kStageChunk * DS_FEATURES_COUNT * sizeof(float)));
         return DS_OK;
     }
     void release()
@@ -688,6 +696,7 @@ struct FeatureStaging {
             if (slot.stream) (void)hipStreamDestroy(slot.stream);
         }
         slots.clear();
+        device = -1;
     }
 };
 
@@ -751,15 +760,24 @@ static int staged_features(const FeatureInputs &in, int device)
     if (ensured != DS_OK) return ensured;
     std::atomic<int64_t> next{0};
     std::atomic<int> failed{DS_OK};
+    FirstError error;   // ds_last_error() is thread-local: a worker's message is carried over to the calling thread
     auto work = [&](int worker) {
-        if (hipSetDevice(device) != hipSuccess) { failed.store(DS_E_HIP); return; }
+        if (hipSetDevice(device) != hipSuccess) {
+            failed.store(DS_E_HIP);
+            error.raise("ds_construct_features: hipSetDevice(%d) failed in a staging thread", device);
+            return;
+        }
         for (;;) {
             const int64_t chunk = next.fetch_add(1, std::memory_order_relaxed);
             if (chunk >= chunks || failed.load(std::memory_order_relaxed) != DS_OK) break;
             const int64_t first = chunk * kStageChunk;
             const int status = stage_chunk(in, staging.slots[static_cast<size_t>(worker)], device, first,
                                            std::min(kStageChunk, in.n - first));
-            if (status != DS_OK) { failed.store(status); break; }
+            if (status != DS_OK) {
+                failed.store(status);
+                error.raise("%s", ds_last_error());
+                break;
+            }
         }
     };
     if (workers <= 1) {
@@ -769,6 +787,7 @@ static int staged_features(const FeatureInputs &in, int device)
         for (int t = 0; t < workers; ++t) pool.emplace_back(work, t);
         for (std::thread &thread : pool) thread.join();
     }
+    if (failed.load() != DS_OK && error.failed()) set_error("%s", error.message());
     return failed.load();
 }
 
