@@ -88,9 +88,9 @@ struct DeviceBuffer {
     int allocate(size_t n)
     {
         release();
-        count = n;
         if (n == 0) return DS_OK;
         DS_HIP(hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T)));
+        count = n;  // only a buffer that exists has a size (a failed allocation leaves {nullptr, 0})
         return DS_OK;
     }
     int upload(const T *host, size_t n)
@@ -132,8 +132,11 @@ struct ds_index {
                                            // signature (bit g = row is in the posting list of the g-th densest column), word 4 =
                                            // sums32 bits, word 5 = duplicate rank (below), words 6..7 unused
     ds::DeviceBuffer<int8_t> sig_column;   // [n_columns] signature bit of a column, -1 for all but the 128 densest
-    ds::DeviceBuffer<int64_t> row_start;   // [n_truth + 1] forward index: row t's columns are row_cols[row_start[t] .. row_start[t + 1])
-    ds::DeviceBuffer<int32_t> row_cols;    // [nnz] ascending column ids per row, rows in internal order (the exact stage's input)
+    ds::DeviceBuffer<unsigned char> row_start;  // [n_truth + 1] forward index: row t's columns are row_cols[row_start[t] .. row_start[t + 1]);
+                                                // uint32 while nnz < 2^32 (forward_wide_start = false), else int64
+    ds::DeviceBuffer<unsigned char> row_cols;   // [nnz] ascending column ids per row, rows in internal order (the exact stage's input);
+                                                // uint16 while n_columns <= 65536 (forward_wide_cols = false), else int32
+    bool forward_wide_start = false, forward_wide_cols = false;
     // duplicate rank of a row (word 5 of its record): rows with the same column set and sums32 bits but a larger index (saturating)
     bool rows_sorted = false;              // internal row order ascends with sums32 (ds_index_create, DS_SORT_ROWS != 0)
     bool literal_only = false;             // idf32 / sums32 hold negative or non-finite values: the bounds of the fast kernel
@@ -151,6 +154,7 @@ struct ds_index {
     hipEvent_t event_begin = nullptr, event_fast = nullptr, event_dense = nullptr;  // per-kernel timing of the last call
     bool attributes_set = false;
     bool count_bytes = false;              // launch the instantiation of the fast kernel that counts its requested bytes
+    bool query_order = true;               // the fast kernel's work queue hands out the queries with most columns first
     int64_t last_queries = 0;
     // last resort of the literal kernel (a query whose near-ties do not fit its LDS buffer): the argument block of the last
     // launch, the geometry's resolver, and a float64[n_truth] scratch vector allocated on first need
@@ -166,4 +170,10 @@ struct ds_titles {
     ds::DeviceBuffer<uint8_t> enc;      // [n][stride]
     ds::DeviceBuffer<uint8_t> len;      // [n]
     ds::DeviceBuffer<uint32_t> counts;  // [n][15] or empty
+    // truth tables: what construct_features derives from the truth title ALONE (word boundaries, idf_s, ranks ...), one 160-byte
+    // record per row for one (number_of_truth_titles, space code); built on the first indexed call that names them
+    ds::DeviceBuffer<unsigned char> records;
+    uint32_t records_n_truth = 0;
+    uint8_t records_space = 0;
+    bool records_enabled = true;        // ds_titles_option("truth_records", 0) switches them off (160 B per row of HBM)
 };

@@ -16,6 +16,7 @@
 //     anti-diagonal DP with uint8 wrap-around, three diagonals staged in LDS, 64 cells per step.
 // All strings, masks and the reconstructed title live in LDS; HBM traffic is the title bytes in and 264 B out.
 #include <cmath>
+#include <cstddef>
 #include <mutex>
 
 #include "ds_common.h"
@@ -36,17 +37,19 @@ struct FeatureArgs {
     const int32_t *pair_t;  // nullable
     const uint32_t *q_off;  // nullable: row i of the titles starts at q_enc + q_off[i] instead of q_enc + i * q_stride
     const uint32_t *t_off;  //           (the packed staging of the host-pointer entry point ships only the titles' own bytes)
+    const unsigned char *t_records;  // nullable: one TruthRecord per truth row (indexed entry points)
     float *out;
     int64_t q_stride, t_stride;
     int64_t n_q, n_t;       // table sizes (bounds for indexes)
     int64_t n;              // pairs
+    int32_t unit_pairs;     // consecutive pairs one wave works through, two at a time (a query's title is staged once for its run of them)
     int64_t q_first;
     int32_t k;              // > 0: pair i belongs to query q_first + i / k (when pair_q is null)
     uint32_t n_truth;
     uint8_t space_code;
 };
 
-struct PairScratch {           // what the features kernel needs per pair (2,848 B)
+struct PairScratch {           // what the features kernel needs per pair (2,752 B)
     unsigned long long masks[64];
     uint8_t q[256];
     uint8_t t[256];
@@ -54,8 +57,8 @@ struct PairScratch {           // what the features kernel needs per pair (2,848
     uint8_t recon[kReconCap];
     uint8_t diag[3][kReconCap];
     float features[72];
-    int32_t word_begin[16];
-    int32_t word_len[16];
+    uint8_t word_begin[16];
+    uint8_t word_len[16];
 };
 struct WaveScratch : PairScratch {
     uint8_t token_begin[128];  // token-sort scratch of the close-match kernel
@@ -245,16 +248,105 @@ __device__ uint8_t levenshtein_g(PairScratch &w, const uint8_t *a, int la, const
     return levenshtein_literal_g(w, a, la, b, lb, gl);
 }
 
-// ratio_from_lcs for every (total length <= 128, LCS <= 64): what the word loop needs (window <= word <= 64 chars)
-constexpr int kRatioLengths = 129, kRatioLcs = 65;
+// ratio_from_lcs for every (total length <= 128, LCS <= 64): what the word loop needs (window <= word <= 64 chars).  The
+// float64 evaluation of :63 costs ~35 instructions per window: tabulated ONCE per device (round 4: once per workgroup, 8 % of
+// the kernel's instructions), a workgroup copies the 8 KiB into LDS.
+constexpr int kRatioLengths = 129, kRatioLcs = 65, kRatioEntries = (kRatioLengths * kRatioLcs + 3) & ~3;
+__device__ uint8_t g_ratio_table[kRatioEntries];
+__global__ __launch_bounds__(256) void ds_ratio_table_kernel()
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < kRatioEntries) g_ratio_table[i] = i < kRatioLengths * kRatioLcs ? ratio_from_lcs(i % kRatioLcs, i / kRatioLcs) : 0;
+}
 
-__global__ __launch_bounds__(kFeatKernelWaves * 64) void ds_construct_features_kernel(FeatureArgs a)
+// What construct_features derives from the TRUTH TITLE alone -- 45 of its 66 outputs and the loop bounds of the rest -- once
+// per truth row instead of once per pair (a truth row is a candidate of 2 queries of C2 on average, of 20 at top-100): the
+// word boundaries of :110-114, truth_number_of_words (:105), idf_s (:153; the float64 log is ~150 instructions) and
+// ranks_idf_s (:158), for one (number_of_truth_titles, space code).  160 bytes per row.
+struct TruthRecord {          // 40 words: a half-wave fetches words 0..31 with ONE load (lane = word), words 32..39 with a second
+    float idf_s[DS_WORDS];    // NaN beyond the title's words (:121-123)
+    float ranks[DS_WORDS];
+    uint8_t n_words;          // words of the title, at most 15 (:114)          } word 30
+    uint8_t small_alphabet;   // every character code of the title is below 64  }
+    uint16_t truth_words;     // spaces + 1 (:105)                              }
+    uint32_t unused;          // word 31
+    uint8_t word_begin[16], word_len[16];   // words 32..35, 36..39 (entry 15 unused)
+};
+static_assert(sizeof(TruthRecord) == 160 && offsetof(TruthRecord, n_words) == 120 && offsetof(TruthRecord, word_begin) == 128 &&
+                  DS_WORDS == 15 && kGroup == 32, "truth records: two loads of a half-wave");
+
+// idf_s of one word (:153) and the ranks of a title's words (:158): the SAME expressions for the records and for the kernel
+// that has none (float64 log of the device library; NaN bit patterns follow x86-64 SSE, the reference's platform: a NaN
+// operand propagates unchanged (+qNaN from the np.nan fill of :121-123), an invalid operation (inf - inf when a word count is
+// 0) produces the default NaN, which has the sign bit set).
+__device__ __forceinline__ float idf_of_word(uint32_t n_truth, uint32_t count)
+{
+    return static_cast<float>(log(static_cast<double>(n_truth) / static_cast<double>(count)));
+}
+__device__ __forceinline__ float nan_max(float maximum, float other)  // np.nanmax, two values at a time
+{
+    return (other != other) ? maximum : ((maximum != maximum || other > maximum) ? other : maximum);
+}
+__device__ __forceinline__ float rank_of_word(float idf, float maximum, int truth_words)
+{
+    if (idf != idf) return __uint_as_float(0x7fc00000u);
+    const float difference = maximum - idf;  // float32 difference, float64 quotient
+    return (difference != difference) ? __uint_as_float(0xffc00000u)
+                                      : static_cast<float>(1.0 + static_cast<double>(difference) / static_cast<double>(truth_words));
+}
+
+// one thread per truth row (a one-time pass over the title table: 13 GB of reads for C5's 50M rows)
+__global__ __launch_bounds__(256) void ds_truth_records_kernel(const uint8_t *enc, int64_t stride, const uint8_t *len,
+                                                               const uint32_t *counts, int64_t n, uint32_t n_truth,
+                                                               uint8_t space, TruthRecord *records)
+{
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= n) return;
+    const uint8_t *title = enc + row * stride;
+    const int lt = len[row];
+    TruthRecord r;
+    int n_words = 0, previous_end = 0, spaces = 0;
+    bool small = true;
+    for (int i = 0; i <= lt; ++i) {  // positions of the spaces of truth + [space], first 15 (:110-114)
+        const uint8_t c = i < lt ? title[i] : space;
+        if (i < lt) {
+            small = small && c < 64;
+            spaces += c == space;
+        }
+        if (c == space && n_words < DS_WORDS) {
+            r.word_begin[n_words] = static_cast<uint8_t>(previous_end);
+            r.word_len[n_words] = static_cast<uint8_t>(i - previous_end);
+            previous_end = i + 1;
+            ++n_words;
+        }
+    }
+    for (int j = n_words; j < 16; ++j) r.word_begin[j] = r.word_len[j] = 0;
+    const int truth_words = spaces + 1;
+    float maximum = __uint_as_float(0x7fc00000u);
+    for (int j = 0; j < DS_WORDS; ++j) {
+        r.idf_s[j] = j < n_words ? idf_of_word(n_truth, counts[row * DS_WORDS + j]) : __uint_as_float(0x7fc00000u);
+        maximum = nan_max(maximum, r.idf_s[j]);
+    }
+    for (int j = 0; j < DS_WORDS; ++j) r.ranks[j] = rank_of_word(r.idf_s[j], maximum, truth_words);
+    r.n_words = static_cast<uint8_t>(n_words);
+    r.small_alphabet = small ? 1 : 0;
+    r.truth_words = static_cast<uint16_t>(truth_words);
+    r.unused = 0u;
+    records[row] = r;
+}
+
+// kRecords: the truth rows come with their TruthRecord (indexed entry points); without them (the 9-argument entry point: the
+// caller's own arrays, every pair its own copy of both titles) the kernel derives everything itself.
+#ifndef DS_FEAT_MIN_WAVES
+#define DS_FEAT_MIN_WAVES 5   // waves per SIMD the register allocation leaves room for (measured: 4 / 5 / 6 -> C2 1.78 / 1.70 / 1.73 ms, top-100 13.0 / 12.2 / 12.7)
+#endif
+template <bool kRecords>
+__global__ __launch_bounds__(kFeatKernelWaves * 64, DS_FEAT_MIN_WAVES) void ds_construct_features_kernel(FeatureArgs a)
 {
     __shared__ PairScratch scratch[kFeatKernelWaves * kPairsPerWave];
-    // the float64 evaluation of :63 costs ~35 instructions per window; a workgroup tabulates it once
-    __shared__ uint8_t ratio_table[kRatioLengths * kRatioLcs];
-    for (int i = threadIdx.x; i < kRatioLengths * kRatioLcs; i += kFeatKernelWaves * 64)
-        ratio_table[i] = ratio_from_lcs(i % kRatioLcs, i / kRatioLcs);
+    __shared__ __align__(4) uint8_t ratio_table[kRatioEntries];
+    for (int i = threadIdx.x; i < kRatioEntries / 4; i += kFeatKernelWaves * 64)
+        reinterpret_cast<uint32_t *>(ratio_table)[i] = reinterpret_cast<const uint32_t *>(g_ratio_table)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, group = kGroup == 32 ? lane >> 5 : lane >> 4, gl = lane & (kGroup - 1);
     PairScratch &w = scratch[(threadIdx.x >> 6) * kPairsPerWave + group];
@@ -262,10 +354,17 @@ __global__ __launch_bounds__(kFeatKernelWaves * 64) void ds_construct_features_k
     const int64_t wave_count = static_cast<int64_t>(gridDim.x) * kFeatKernelWaves;
     const uint8_t space = a.space_code;
     const float nan = __uint_as_float(0x7fc00000u);
+    const int64_t unit_pairs = a.unit_pairs;
 
-    for (int64_t first_pair = wave_global * kPairsPerWave; first_pair < a.n; first_pair += wave_count * kPairsPerWave) {
-        const int64_t pair = first_pair + group;
-        if (pair >= a.n) continue;  // the odd last pair: the upper half idles (no wave-wide collective below needs it)
+    // A wave works through UNITS of `unit_pairs` consecutive pairs, its halves taking alternate pairs: the k candidates of a
+    // query are consecutive, so a half stages the query's title (copy, count, squeeze) once for its share of the run -- and
+    // both halves work on the SAME query, whose length sets the trip counts of the loops they walk together.
+    for (int64_t unit = wave_global; unit * unit_pairs < a.n; unit += wave_count) {
+        int64_t staged_query = -1;
+        int lq = 0, lw = 0, title_words = 0;
+        bool small_q = false;
+        const int64_t unit_end = min(a.n, (unit + 1) * unit_pairs);
+        for (int64_t pair = unit * unit_pairs + group; pair < unit_end; pair += kPairsPerWave) {
         float *out = a.out + pair * DS_FEATURES_COUNT;
         const int64_t qi = a.pair_q ? a.pair_q[pair] : (a.k > 0 ? a.q_first + pair / a.k : pair);
         const int64_t ti = a.pair_t ? a.pair_t[pair] : pair;
@@ -279,35 +378,68 @@ __global__ __launch_bounds__(kFeatKernelWaves * 64) void ds_construct_features_k
             }
             continue;
         }
-        const int lq = a.q_len[qi], lt = a.t_len[ti];                                      // :101-102
-        const uint8_t *gq = a.q_enc + (a.q_off ? static_cast<int64_t>(a.q_off[qi]) : qi * a.q_stride);
+        const int lt = a.t_len[ti];                                                        // :102
         const uint8_t *gt = a.t_enc + (a.t_off ? static_cast<int64_t>(a.t_off[ti]) : ti * a.t_stride);
-        wave_sync();
-        // stage both strings; count spaces; squeeze the spaces out of the title (:104-108)
-        int spaces_q = 0, spaces_t = 0, lw = 0;
-        const int longest = lq > lt ? lq : lt;
-        for (int base = 0; base < longest; base += kGroup) {
-            const int i = base + gl;
-            const uint8_t cq = i < lq ? gq[i] : 0;
-            const uint8_t ct = i < lt ? gt[i] : 0;
-            if (i < 256) {
-                w.q[i] = cq;
-                w.t[i] = ct;
-            }
-            const bool is_char = i < lq && cq != space;
-            const uint32_t keep = group_ballot(is_char, group);
-            if (is_char) w.qw[lw + __popc(keep & ((1u << gl) - 1u))] = cq;
-            lw += __popc(keep);
-            spaces_q += __popc(group_ballot(i < lq && cq == space, group));
-            spaces_t += __popc(group_ballot(i < lt && ct == space, group));
+        // the record: words 0..31 (idf_s, ranks, the counts word) and 32..39 (word boundaries), requested here, used behind the
+        // staging.  (Round 5 also kept three pairs in flight -- indexes two pairs ahead, row data one pair ahead: no gain, the
+        // waves do not wait for these loads; profiles/r05_tuning.txt.)
+        uint32_t record_low = 0, record_high = 0;
+        if constexpr (kRecords) {
+            const uint32_t *record = reinterpret_cast<const uint32_t *>(reinterpret_cast<const TruthRecord *>(a.t_records) + ti);
+            record_low = record[gl];
+            if (gl < 8) record_high = record[32 + gl];
         }
         wave_sync();
-        const int title_words = spaces_q + 1, truth_words = spaces_t + 1;
-        const bool small_alphabet = codes_below_64_g(w.q, lq, gl, group) && codes_below_64_g(w.t, lt, gl, group);
-
-        // truth word boundaries: positions of the spaces of truth + [space], first 15 (:110-114)
-        int n_words = 0;
-        {
+        if (qi != staged_query) {
+            // stage the title; count its spaces; squeeze them out (:101, :104, :108)
+            staged_query = qi;
+            lq = a.q_len[qi];
+            const uint8_t *gq = a.q_enc + (a.q_off ? static_cast<int64_t>(a.q_off[qi]) : qi * a.q_stride);
+            int spaces_q = 0;
+            bool small = true;
+            lw = 0;
+            for (int base = 0; base < lq; base += kGroup) {
+                const int i = base + gl;
+                const uint8_t cq = i < lq ? gq[i] : 0;
+                if (i < 256) w.q[i] = cq;
+                small &= cq < 64;
+                const bool is_char = i < lq && cq != space;
+                const uint32_t keep = group_ballot(is_char, group);
+                if (is_char) w.qw[lw + __popc(keep & ((1u << gl) - 1u))] = cq;
+                lw += __popc(keep);
+                spaces_q += __popc(group_ballot(i < lq && cq == space, group));
+            }
+            title_words = spaces_q + 1;
+            small_q = group_ballot(!small, group) == 0u;
+        }
+        // stage the truth title (:102, :105)
+        int spaces_t = 0;
+        bool small_t = true;
+        for (int base = 0; base < lt; base += kGroup) {
+            const int i = base + gl;
+            const uint8_t ct = i < lt ? gt[i] : 0;
+            if (i < 256) w.t[i] = ct;
+            if constexpr (!kRecords) {
+                small_t &= ct < 64;
+                spaces_t += __popc(group_ballot(i < lt && ct == space, group));
+            }
+        }
+        wave_sync();
+        int truth_words, n_words = 0;
+        bool small_alphabet;
+        float record_idf = nan, record_rank = nan;
+        if constexpr (kRecords) {
+            const uint32_t record_tail = static_cast<uint32_t>(__shfl(static_cast<int>(record_low), 30, kGroup));
+            n_words = static_cast<int>(record_tail & 0xffu);
+            small_alphabet = small_q && ((record_tail >> 8) & 0xffu) != 0u;
+            truth_words = static_cast<int>(record_tail >> 16);
+            record_idf = __uint_as_float(record_low);                                                    // lanes 0..14
+            record_rank = __uint_as_float(static_cast<uint32_t>(__shfl(static_cast<int>(record_low), (gl + DS_WORDS) & 31, kGroup)));
+            if (gl < 8) reinterpret_cast<uint32_t *>(w.word_begin)[gl] = record_high;  // word_begin[16] and word_len[16] are adjacent
+        } else {
+            truth_words = spaces_t + 1;
+            small_alphabet = small_q && group_ballot(!small_t, group) == 0u;
+            // truth word boundaries: positions of the spaces of truth + [space], first 15 (:110-114)
             int previous_end = 0;  // start of the current word
             for (int base = 0; base <= lt && n_words < DS_WORDS; base += kGroup) {
                 const int i = base + gl;
@@ -316,8 +448,8 @@ __global__ __launch_bounds__(kFeatKernelWaves * 64) void ds_construct_features_k
                 while (votes && n_words < DS_WORDS) {
                     const int position = base + __ffs(votes) - 1;
                     if (gl == 0) {
-                        w.word_begin[n_words] = previous_end;
-                        w.word_len[n_words] = position - previous_end;
+                        w.word_begin[n_words] = static_cast<uint8_t>(previous_end);
+                        w.word_len[n_words] = static_cast<uint8_t>(position - previous_end);
                     }
                     previous_end = position + 1;
                     ++n_words;
@@ -333,7 +465,12 @@ __global__ __launch_bounds__(kFeatKernelWaves * 64) void ds_construct_features_k
         if (gl < DS_WORDS) {
             w.features[6 + gl] = nan;
             w.features[6 + DS_WORDS + gl] = nan;
-            w.features[6 + 2 * DS_WORDS + gl] = nan;
+            if constexpr (kRecords) {
+                w.features[6 + 2 * DS_WORDS + gl] = record_idf;    // :153
+                w.features[6 + 3 * DS_WORDS + gl] = record_rank;   // :158
+            } else {
+                w.features[6 + 2 * DS_WORDS + gl] = nan;
+            }
         }
         int lr = 0;
         if (gl == 0) w.recon[0] = space;  // :115
@@ -384,37 +521,22 @@ __global__ __launch_bounds__(kFeatKernelWaves * 64) void ds_construct_features_k
             wave_sync();
         }
 
-        // :153  idf_s of every word at once, one lane per word (the float64 log is ~150 instructions: evaluated once
-        // per pair for all lanes instead of once per word on a single lane)
-        if (gl < n_words)
-            w.features[6 + 2 * DS_WORDS + gl] = static_cast<float>(
-                log(static_cast<double>(a.n_truth) / static_cast<double>(a.t_counts[ti * DS_WORDS + gl])));
-        wave_sync();
+        if constexpr (!kRecords) {
+            // :153  idf_s of every word at once, one lane per word (the float64 log is ~150 instructions: evaluated once
+            // per pair for all lanes instead of once per word on a single lane)
+            if (gl < n_words) w.features[6 + 2 * DS_WORDS + gl] = idf_of_word(a.n_truth, a.t_counts[ti * DS_WORDS + gl]);
+            wave_sync();
+        }
 
         // :161-162  strip the first and the last space
         const uint8_t recon_ratio = levenshtein_g(w, w.recon + 1, lr - 2, w.t, lt, gl, small_alphabet);
 
-        // :158  ranks = 1 + (nanmax(idf_s) - idf_s) / truth_number_of_words   (float32 difference, float64 quotient)
-        float idf = gl < DS_WORDS ? w.features[6 + 2 * DS_WORDS + gl] : nan;
-        float maximum = idf;
-        for (int offset = 8; offset > 0; offset >>= 1) {
-            const float other = __shfl_xor(maximum, offset, 16);
-            maximum = (other != other) ? maximum : ((maximum != maximum || other > maximum) ? other : maximum);
-        }
-        if (gl < DS_WORDS) {
-            // NaN bit patterns follow x86-64 SSE (the reference's platform): a NaN operand propagates unchanged
-            // (+qNaN from the np.nan fill of :121-123), an invalid operation (inf - inf when a word count is 0)
-            // produces the default NaN, which has the sign bit set.
-            float rank;
-            if (idf != idf) {
-                rank = nan;
-            } else {
-                const float difference = maximum - idf;
-                rank = (difference != difference)
-                           ? __uint_as_float(0xffc00000u)
-                           : static_cast<float>(1.0 + static_cast<double>(difference) / static_cast<double>(truth_words));
-            }
-            w.features[6 + 3 * DS_WORDS + gl] = rank;
+        if constexpr (!kRecords) {
+            // :158  ranks = 1 + (nanmax(idf_s) - idf_s) / truth_number_of_words
+            const float idf = gl < DS_WORDS ? w.features[6 + 2 * DS_WORDS + gl] : nan;
+            float maximum = idf;
+            for (int offset = 8; offset > 0; offset >>= 1) maximum = nan_max(maximum, __shfl_xor(maximum, offset, 16));
+            if (gl < DS_WORDS) w.features[6 + 3 * DS_WORDS + gl] = rank_of_word(idf, maximum, truth_words);
         }
         if (gl == 0) {  // :164-167
             w.features[0] = static_cast<float>(lq);
@@ -433,6 +555,7 @@ __global__ __launch_bounds__(kFeatKernelWaves * 64) void ds_construct_features_k
 #pragma unroll
             for (int i = 0; i < DS_FEATURES_COUNT; i += kGroup)
                 if (i + gl < DS_FEATURES_COUNT) out[i + gl] = w.features[i + gl];
+        }
         }
     }
 }
@@ -738,7 +861,7 @@ static int stage_chunk(const FeatureInputs &in, FeatureSlot &slot, int device, i
     args.q_off = reinterpret_cast<const uint32_t *>(slot.d_in + 2 * m4);
     args.t_off = reinterpret_cast<const uint32_t *>(slot.d_in + 6 * m4);
     args.t_counts = reinterpret_cast<const uint32_t *>(slot.d_in + 10 * m4);
-    args.pair_q = nullptr; args.pair_t = nullptr; args.out = slot.d_out;
+    args.pair_q = nullptr; args.pair_t = nullptr; args.out = slot.d_out; args.t_records = nullptr; args.unit_pairs = 2;
     args.q_stride = 0; args.t_stride = 0; args.n_q = m; args.n_t = m; args.n = m; args.q_first = 0; args.k = 0;
     args.n_truth = in.n_truth; args.space_code = in.space_code;
     const int status = launch_features(args, device, slot.stream);
@@ -794,13 +917,64 @@ static int staged_features(const FeatureInputs &in, int device)
 static int launch_features(const FeatureArgs &args, int device, hipStream_t stream)
 {
     if (args.n == 0) return DS_OK;
-    (void)device;
-    const int64_t pairs_per_block = kPairsPerWave * kFeatKernelWaves;
-    const int64_t blocks_needed = (args.n + pairs_per_block - 1) / pairs_per_block;
-    const int grid = static_cast<int>(std::min<int64_t>(blocks_needed, 256 * 32));
-    hipLaunchKernelGGL(ds_construct_features_kernel, dim3(grid), dim3(kFeatKernelWaves * 64), 0, stream, args);
+    {   // the ratio table of this device: once per process, complete before any stream's first kernel reads it
+        static std::mutex mutex;
+        static bool ready[64] = {false};
+        std::lock_guard<std::mutex> guard(mutex);
+        if (device >= 0 && device < 64 && !ready[device]) {
+            hipLaunchKernelGGL(ds_ratio_table_kernel, dim3((kRatioEntries + 255) / 256), dim3(256), 0, stream);
+            DS_HIP(hipGetLastError());
+            DS_HIP(hipStreamSynchronize(stream));
+            ready[device] = true;
+        }
+    }
+    // Persistent waves, every one with the SAME number of units (+- 1): 32,768 waves at most, and as many fewer as keep the
+    // last round full (100,000 units on 65,536 waves would take two rounds with a third of the chip idle in the second).
+    const int64_t units = (args.n + args.unit_pairs - 1) / args.unit_pairs;
+    const int64_t most_waves = 256 * 32 * kFeatKernelWaves;
+    const int64_t rounds = (units + most_waves - 1) / most_waves;
+    const int64_t waves = (units + rounds - 1) / rounds;
+    const int grid = static_cast<int>((waves + kFeatKernelWaves - 1) / kFeatKernelWaves);
+    if (args.t_records != nullptr)
+        hipLaunchKernelGGL(ds_construct_features_kernel<true>, dim3(grid), dim3(kFeatKernelWaves * 64), 0, stream, args);
+    else
+        hipLaunchKernelGGL(ds_construct_features_kernel<false>, dim3(grid), dim3(kFeatKernelWaves * 64), 0, stream, args);
     DS_HIP(hipGetLastError());
     return DS_OK;
+}
+
+// The truth table's records for (n_truth, space code): built on `stream` in front of the first launch that names them.
+static int ensure_truth_records(ds_titles *truth, uint32_t n_truth, uint8_t space_code, hipStream_t stream)
+{
+    if (!truth->records_enabled) return DS_OK;
+    const size_t bytes = static_cast<size_t>(truth->n) * sizeof(TruthRecord);
+    if (truth->records.count == bytes && truth->records_n_truth == n_truth && truth->records_space == space_code) return DS_OK;
+    if (truth->records.count != bytes) {
+        const int allocated = truth->records.allocate(bytes);
+        if (allocated != DS_OK) {   // not enough HBM for them: the kernel derives everything per pair, as before
+            truth->records.release();
+            truth->records_enabled = false;
+            (void)hipGetLastError();
+            return DS_OK;
+        }
+    }
+    hipLaunchKernelGGL(ds_truth_records_kernel, dim3(static_cast<unsigned>((truth->n + 255) / 256)), dim3(256), 0, stream,
+                       truth->enc.ptr, truth->stride, truth->len.ptr, truth->counts.ptr, truth->n, n_truth, space_code,
+                       reinterpret_cast<TruthRecord *>(truth->records.ptr));
+    DS_HIP(hipGetLastError());
+    truth->records_n_truth = n_truth;
+    truth->records_space = space_code;
+    return DS_OK;
+}
+
+// consecutive pairs one wave works through (two at a time): the k candidates of a query (k <= 16), a divisor of k between 8 and 16, or 10
+static int32_t pairs_per_unit(int32_t k)
+{
+    if (k <= 0) return 8;
+    if (k <= 16) return k;
+    for (int32_t d = 16; d >= 8; --d)
+        if (k % d == 0) return d;
+    return 10;
 }
 
 }  // namespace ds
@@ -856,6 +1030,22 @@ int ds_titles_create(const uint8_t *enc, int64_t stride, const uint8_t *len, con
     return DS_OK;
 }
 
+int ds_titles_option(ds_titles *titles, const char *name, int64_t value)
+{
+    DS_REQUIRE(titles && name, "ds_titles_option: null argument");
+    if (std::strcmp(name, "truth_records") == 0) {   // 160 bytes of HBM per truth row for what depends on the truth title alone
+        titles->records_enabled = value != 0;
+        if (!titles->records_enabled) {
+            DS_HIP(hipSetDevice(titles->device));
+            DS_HIP(hipDeviceSynchronize());
+            titles->records.release();
+        }
+        return DS_OK;
+    }
+    ds::set_error("ds_titles_option: unknown option '%s'", name);
+    return DS_E_ARG;
+}
+
 void ds_titles_destroy(ds_titles *titles)
 {
     if (!titles) return;
@@ -881,6 +1071,11 @@ int ds_construct_features_indexed_device(ds_titles *queries, ds_titles *truth, c
     args.out = d_out; args.q_stride = queries->stride; args.t_stride = truth->stride; args.n_q = queries->n;
     args.n_t = truth->n; args.n = n; args.q_first = q_first; args.k = d_pair_q ? 0 : k; args.n_truth = n_truth;
     args.space_code = space_code;
+    // a caller that switches between streams orders them itself (the records are written once per (n_truth, space code))
+    const int ensured = ds::ensure_truth_records(truth, n_truth, space_code, static_cast<hipStream_t>(stream));
+    if (ensured != DS_OK) return ensured;
+    args.t_records = truth->records_enabled ? truth->records.ptr : nullptr;
+    args.unit_pairs = ds::pairs_per_unit(d_pair_q ? 0 : k);
     return ds::launch_features(args, truth->device, static_cast<hipStream_t>(stream));
 }
 

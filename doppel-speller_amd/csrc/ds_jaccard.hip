@@ -50,6 +50,10 @@ int ds_index_option(ds_index *index, const char *name, int64_t value)
         index->count_bytes = value != 0;
         return DS_OK;
     }
+    if (std::strcmp(name, "query_order") == 0) {  // 1 (default): the work queue hands out the queries with most columns first
+        index->query_order = value != 0;
+        return DS_OK;
+    }
     ds::set_error("ds_index_option: unknown option '%s'", name);
     return DS_E_ARG;
 }

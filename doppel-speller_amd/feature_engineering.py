@@ -147,6 +147,10 @@ class TitleTable:
                                                counts_ptr, self.n, device, ctypes.byref(self.handle)),
                    "ds_titles_create")
 
+    def option(self, name, value):
+        """ds_titles_option, e.g. option("truth_records", 0): no per-row records of the truth-only features (160 B of HBM per row)."""
+        _lib.check(_lib.lib().ds_titles_option(self.handle, name.encode(), int(value)), "ds_titles_option")
+
     def close(self):
         if self.handle:
             _lib.lib().ds_titles_destroy(self.handle)

@@ -74,9 +74,15 @@ int ds_index_image_digest(const int64_t *rowptr, const int32_t *truth_idx, const
                           int64_t V, int64_t N, int64_t tile_rows, uint64_t digest[8]);
 /* Diagnostics switches of an index.  "count_bytes" (0 / 1): the next ds_jaccard_topk* calls run the instantiation of
  * the fast kernel that also counts the bytes it requests from global memory (reported by ds_jaccard_sync, stats[15]);
- * same work, same results, about 3 % slower -- bench.py runs it once outside the timed region for its roofline. */
+ * same work, same results, about 3 % slower -- bench.py runs it once outside the timed region for its roofline.
+ * "query_order" (1 / 0, default 1): the fast kernel's work queue hands out the queries with most columns first (a device-side
+ * counting sort; 0 = the caller's order; answers do not depend on it).
+ * The product's launches read NOTHING from the environment.  Environment read by ds_index_create / the host builds only
+ * (tests and A/B measurements): DS_HOST_THREADS, DS_BUILD_LOG=1, DS_SORT_ROWS=0, DS_GEOMETRY=narrow|wide.  The kernels'
+ * tuning knobs (DS_SPARSE_QUADS, DS_SELECT_*, DS_DEBUG, DS_PHASE_TIMERS / DS_PHASE_DUMP) exist in -DDS_DIAGNOSTICS builds only. */
 int ds_index_option(ds_index *index, const char *name, int64_t value);
-/* info[0]=N info[1]=V info[2]=nnz info[3]=tile size info[4]=tiles info[5]=device bytes info[6]=padded postings */
+/* info[0]=N info[1]=V info[2]=nnz info[3]=tile size info[4]=tiles info[5]=device bytes info[6]=padded postings
+ * info[7]=bytes of the forward index (row starts uint32 while nnz < 2^32, columns uint16 while V <= 65536), part of info[5] */
 int ds_index_info(const ds_index *index, int64_t info[8]);
 
 /* ---- Jaccard top-k:  fast_jaccard + fast_arg_top_k (match_maker.py:16-71) behind get_closest_matches (:192-203) - */
@@ -127,6 +133,10 @@ int ds_construct_features(const uint8_t *q_len, const uint8_t *t_len, const uint
 int ds_titles_create(const uint8_t *enc, int64_t stride, const uint8_t *len, const uint32_t *word_counts, int64_t n,
                      int device, ds_titles **out);
 void ds_titles_destroy(ds_titles *titles);
+/* "truth_records" (default 1): the indexed entry points keep, per row of a TRUTH table, what construct_features derives from
+ * the truth title alone (word boundaries, idf_s, ranks: feature_engineering.py:110-123,152-158) -- 160 bytes of HBM per row,
+ * built on the first call that names (number_of_truth_titles, space_code).  0 frees them: everything per pair again. */
+int ds_titles_option(ds_titles *titles, const char *name, int64_t value);
 /* Pairs given as (query row, truth row) indexes into two tables: out[i] = construct_features(q[pair_q[i]],
  * t[pair_t[i]]).  Host pointers for pair_q / pair_t / out. */
 int ds_construct_features_indexed(ds_titles *queries, ds_titles *truth, const int32_t *pair_q, const int32_t *pair_t,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds variants/lib_<name>.so from a git revision's csrc/ (or the working tree with rev = WORK): A/B partner for scripts/ab.sh.
+# Builds variants/lib_<name>.so from a git revision's csrc/ (or the working tree with rev = WORK): A/B partner for scripts/ab_r04.sh.
 # Usage: bash scripts/build_variant.sh <name> <rev|WORK> [extra hipcc flags]
 name=$1; rev=$2; shift 2
 dir=/tmp/variant_$name; rm -rf $dir; mkdir -p $dir variants

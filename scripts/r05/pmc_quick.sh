@@ -16,11 +16,11 @@ tot = collections.defaultdict(float); calls = collections.Counter(); dur = []
 for name in ("sq1", "sq2"):
     for path in glob.glob("gpurun_out/pmcq_${tag}_%s/**/*counter_collection.csv" % name, recursive=True):
         for row in csv.DictReader(open(path)):
-            if "ds_jaccard_topk_kernel" not in row["Kernel_Name"]: continue
+            if "${KERNEL:-ds_jaccard_topk_kernel}" not in row["Kernel_Name"]: continue
             tot[row["Counter_Name"]] += float(row["Counter_Value"]); calls[row["Counter_Name"]] += 1
     for path in glob.glob("gpurun_out/pmcq_${tag}_%s/**/*kernel_trace.csv" % name, recursive=True):
         for row in csv.DictReader(open(path)):
-            if "ds_jaccard_topk_kernel" in row["Kernel_Name"]: dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            if "${KERNEL:-ds_jaccard_topk_kernel}" in row["Kernel_Name"]: dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
 n_disp = {c: calls[c] for c in calls}
 per = {c: tot[c] / max(1, len(dur) // 2) for c in tot}   # per launch (each pass sees the same launches)
 print("launches per pass", len(dur) // 2, "mean ms", sum(dur) / len(dur) / 1e6)

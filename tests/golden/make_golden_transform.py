@@ -37,3 +37,26 @@ vectors = [{"title": t, "transformed": common.transform_title(t)} for t in title
 with open(os.path.join(HERE, "transform_title.json"), "w", encoding="utf-8") as out:
     json.dump(vectors, out, ensure_ascii=True, indent=0)
 print(len(vectors), "vectors;", sum(1 for v in vectors if not v["title"].isascii()), "with non-ASCII input")
+
+# ---- the three vectors the reference's OWN tests hold (doppelspeller/tests/test_common.py:16-28), captured as data: the inputs
+# are those of its test case, the outputs what its functions return here (asserted equal to the values its tests expect).
+import pandas as pd  # noqa: E402
+from doppelspeller import constants as c  # noqa: E402
+
+kat_title = '''LKJblksd skjasl dfkjf &* 8*&&&8 GGdjsdkj--sdsd-"sdi..//' d'  k   bkjh77_asda33'''
+ground_truth = [['first', 'second', 'first', 'third', 'first'], ['first', 'first'], ['fifth']]
+frame = pd.DataFrame(index=range(len(ground_truth)))
+frame.loc[:, c.COLUMN_WORDS] = ground_truth
+counter = common.get_words_counter(frame)
+reference_tests = {
+    "transform_title": {"title": kat_title, "transformed": common.transform_title(kat_title)},
+    "words_counter": {"titles_as_words": ground_truth, "counts": dict(counter)},
+    "idf_word": {"word": "first", "number_of_titles": len(ground_truth), "count": counter["first"],
+                 "idf": common.idf_word("first", counter, len(ground_truth))},
+}
+assert reference_tests["transform_title"]["transformed"] == 'lkjblksd skjasl dfkjf 88 ggdjsdkj sdsd sdi d k bkjh77asda33'
+assert reference_tests["words_counter"]["counts"] == {'first': 2, 'second': 1, 'third': 1, 'fifth': 1}
+assert round(reference_tests["idf_word"]["idf"], 5) == 0.40547
+with open(os.path.join(HERE, "reference_tests.json"), "w", encoding="utf-8") as out:
+    json.dump(reference_tests, out, ensure_ascii=True, indent=1)
+print("reference_tests.json:", reference_tests["idf_word"])

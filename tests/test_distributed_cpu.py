@@ -69,7 +69,7 @@ def _worker(rank, world, port, n_queries, result_path):
     rendezvous.close()
 
 
-@pytest.mark.parametrize("world,n_queries", [(2, 64), (2, 65), (3, 100)])
+@pytest.mark.parametrize("world,n_queries", [(2, 64), (2, 65), (3, 100), (8, 1001)])   # 8 = the node the driver runs C4 / C5 on
 def test_gather_matches_single_process(tmp_path, world, n_queries):
     from doppel_speller_amd import synth
     from oracle import oracle
@@ -278,3 +278,51 @@ def test_published_workload_round_trip(tmp_path):
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     assert synth.algorithmic_bytes_jaccard(mapped, 10, begin, end) + synth.algorithmic_bytes_jaccard(mapped, 10, 0, begin) == \
         synth.algorithmic_bytes_jaccard(w, 10)
+
+
+def _published_worker(rank, world, port, shared, out_path):
+    """One rank of bench.py's N > 1 flow on the CPU: rank 0 generates and publishes the workload, every rank maps it, takes
+    its (uneven) query shard, answers it with the oracle and all-gathers the rows."""
+    sys.path.insert(0, ROOT)
+    from doppel_speller_amd import synth
+    from doppel_speller_amd.distributed import HostCommunicator, Rendezvous, RowGather, shard_range, slice_queries
+    from oracle import oracle
+    rendezvous = Rendezvous(rank, world, port=port)
+    if rank == 0:
+        synth.publish_workload(synth.make_workload(2500, 1003, seed=23), shared)
+    rendezvous.barrier()
+    w = synth.load_workload(shared)
+    begin, end = shard_range(w.n_queries, rank, world)
+    rowptr, cols, maxint = slice_queries(w.q_rowptr, w.q_cols, w.q_maxint, begin, end)
+    local = oracle.jaccard_topk(w.rowptr, w.truth_idx, w.idf32, w.sums32, rowptr, cols, maxint, 7)
+    gathered = RowGather(HostCommunicator(rendezvous), w.n_queries, 7).gather(local)
+    sizes = rendezvous.all_gather_bytes(str(end - begin).encode())
+    rendezvous.barrier()
+    np.save(f"{out_path}.{rank}.npy", gathered)
+    with open(f"{out_path}.{rank}.sizes", "w") as handle:
+        handle.write(" ".join(size.decode() for size in sizes))
+    rendezvous.close()
+
+
+def test_eight_ranks_share_one_published_workload_with_uneven_shards(tmp_path):
+    """World size 8 -- the node BASELINE.json's C4 / C5 name -- end to end on the CPU: one published workload, 1003 queries
+    over 8 ranks (shards of 126 and 125), the all-gather of every rank == one process over all the queries."""
+    from doppel_speller_amd import synth
+    from oracle import oracle
+    oracle.build()
+    world, port = 8, _free_port()
+    shared, result = str(tmp_path / "shared"), str(tmp_path / "rows")
+    context = multiprocessing.get_context("spawn")
+    ranks = [context.Process(target=_published_worker, args=(r, world, port, shared, result)) for r in range(world)]
+    for process in ranks:
+        process.start()
+    for process in ranks:
+        process.join(300)
+        assert process.exitcode == 0
+    w = synth.make_workload(2500, 1003, seed=23)
+    expected = oracle.jaccard_topk(w.rowptr, w.truth_idx, w.idf32, w.sums32, w.q_rowptr, w.q_cols, w.q_maxint, 7)
+    for rank in range(world):
+        assert np.array_equal(np.load(f"{result}.{rank}.npy"), expected)
+        with open(f"{result}.{rank}.sizes") as handle:
+            sizes = [int(x) for x in handle.read().split()]
+        assert sum(sizes) == 1003 and sorted(set(sizes)) == [125, 126]

@@ -452,10 +452,10 @@ def test_a_column_listed_twice_in_a_query(oracle, k):
 
 
 @pytest.mark.parametrize("order", ["0", "1"])
-def test_work_queue_order_does_not_change_answers(oracle, monkeypatch, order):
-    """The fast kernel takes the queries with most columns first (a device-side counting sort, DS_QUERY_ORDER=0 switches it
-    off): every query is answered exactly once either way, including queries without columns and with > 128 columns."""
-    monkeypatch.setenv("DS_QUERY_ORDER", order)
+def test_work_queue_order_does_not_change_answers(oracle, order):
+    """The fast kernel takes the queries with most columns first (a device-side counting sort, ds_index_option
+    "query_order" = 0 switches it off): every query is answered exactly once either way, including queries without columns
+    and with > 128 columns."""
     rng = np.random.RandomState(77)
     problem = _random_problem(rng, 30000, 1500, 700, mean_cols=12)
     n_columns = problem["rowptr"].shape[0] - 1
@@ -473,5 +473,11 @@ def test_work_queue_order_does_not_change_answers(oracle, monkeypatch, order):
             total = total + float(value)
         maxint.append(max(total, 1e-3))
     problem["q_maxint"] = np.array(maxint)
-    index = _check(oracle, problem, 10)
+    import doppel_speller_amd as ds
+    index = ds.TruthIndex(problem["rowptr"], problem["truth_idx"], problem["idf32"], problem["sums32"])
+    index.option("query_order", int(order))
+    got = index.top_k(problem["q_rowptr"], problem["q_cols"], problem["q_maxint"], 10)
+    expected = oracle.jaccard_topk(problem["rowptr"], problem["truth_idx"], problem["idf32"], problem["sums32"],
+                                   problem["q_rowptr"], problem["q_cols"], problem["q_maxint"], 10)
+    assert np.array_equal(got, expected)
     assert index.sync()["error_queries"] == 0
