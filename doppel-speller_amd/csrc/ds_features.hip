@@ -38,6 +38,8 @@ struct FeatureArgs {
     const uint32_t *q_off;  // nullable: row i of the titles starts at q_enc + q_off[i] instead of q_enc + i * q_stride
     const uint32_t *t_off;  //           (the packed staging of the host-pointer entry point ships only the titles' own bytes)
     const unsigned char *t_records;  // nullable: one TruthRecord per truth row (indexed entry points)
+    int32_t *unit_queue;             // nullable: head of the work queue of units (zeroed in front of the launch); without it the
+                                     // units are dealt round-robin
     float *out;
     int64_t q_stride, t_stride;
     int64_t n_q, n_t;       // table sizes (bounds for indexes)
@@ -359,7 +361,13 @@ __global__ __launch_bounds__(kFeatKernelWaves * 64, DS_FEAT_MIN_WAVES) void ds_c
     // A wave works through UNITS of `unit_pairs` consecutive pairs, its halves taking alternate pairs: the k candidates of a
     // query are consecutive, so a half stages the query's title (copy, count, squeeze) once for its share of the run -- and
     // both halves work on the SAME query, whose length sets the trip counts of the loops they walk together.
-    for (int64_t unit = wave_global; unit * unit_pairs < a.n; unit += wave_count) {
+    for (int64_t unit = wave_global;; unit += wave_count) {
+        if (a.unit_queue != nullptr) {  // the waves pull their units from a queue: nobody idles while units are left
+            int next = 0;
+            if (lane == 0) next = atomicAdd(a.unit_queue, 1);
+            unit = __builtin_amdgcn_readfirstlane(next);
+        }
+        if (unit * unit_pairs >= a.n) break;  // (reached by every wave: the queue head only grows)
         int64_t staged_query = -1;
         int lq = 0, lw = 0, title_words = 0;
         bool small_q = false;
@@ -861,7 +869,7 @@ static int stage_chunk(const FeatureInputs &in, FeatureSlot &slot, int device, i
     args.q_off = reinterpret_cast<const uint32_t *>(slot.d_in + 2 * m4);
     args.t_off = reinterpret_cast<const uint32_t *>(slot.d_in + 6 * m4);
     args.t_counts = reinterpret_cast<const uint32_t *>(slot.d_in + 10 * m4);
-    args.pair_q = nullptr; args.pair_t = nullptr; args.out = slot.d_out; args.t_records = nullptr; args.unit_pairs = 2;
+    args.pair_q = nullptr; args.pair_t = nullptr; args.out = slot.d_out; args.t_records = nullptr; args.unit_queue = nullptr; args.unit_pairs = 2;
     args.q_stride = 0; args.t_stride = 0; args.n_q = m; args.n_t = m; args.n = m; args.q_first = 0; args.k = 0;
     args.n_truth = in.n_truth; args.space_code = in.space_code;
     const int status = launch_features(args, device, slot.stream);
@@ -928,13 +936,20 @@ static int launch_features(const FeatureArgs &args, int device, hipStream_t stre
             ready[device] = true;
         }
     }
-    // Persistent waves, every one with the SAME number of units (+- 1): 32,768 waves at most, and as many fewer as keep the
-    // last round full (100,000 units on 65,536 waves would take two rounds with a third of the chip idle in the second).
     const int64_t units = (args.n + args.unit_pairs - 1) / args.unit_pairs;
-    const int64_t most_waves = 256 * 32 * kFeatKernelWaves;
-    const int64_t rounds = (units + most_waves - 1) / most_waves;
-    const int64_t waves = (units + rounds - 1) / rounds;
-    const int grid = static_cast<int>((waves + kFeatKernelWaves - 1) / kFeatKernelWaves);
+    int grid;
+    if (args.unit_queue != nullptr) {
+        // as many workgroups as the device holds at once (5 per CU: registers and 31 KiB of LDS each); the queue does the rest
+        DS_HIP(hipMemsetAsync(args.unit_queue, 0, sizeof(int32_t), stream));
+        grid = static_cast<int>(std::min<int64_t>((units + kFeatKernelWaves - 1) / kFeatKernelWaves, 256 * DS_FEAT_MIN_WAVES));
+    } else {
+        // Persistent waves, every one with the SAME number of units (+- 1): 32,768 waves at most, and as many fewer as keep the
+        // last round full (100,000 units on 65,536 waves would take two rounds with a third of the chip idle in the second).
+        const int64_t most_waves = 256 * 32 * kFeatKernelWaves;
+        const int64_t rounds = (units + most_waves - 1) / most_waves;
+        const int64_t waves = (units + rounds - 1) / rounds;
+        grid = static_cast<int>((waves + kFeatKernelWaves - 1) / kFeatKernelWaves);
+    }
     if (args.t_records != nullptr)
         hipLaunchKernelGGL(ds_construct_features_kernel<true>, dim3(grid), dim3(kFeatKernelWaves * 64), 0, stream, args);
     else
@@ -1075,6 +1090,8 @@ int ds_construct_features_indexed_device(ds_titles *queries, ds_titles *truth, c
     const int ensured = ds::ensure_truth_records(truth, n_truth, space_code, static_cast<hipStream_t>(stream));
     if (ensured != DS_OK) return ensured;
     args.t_records = truth->records_enabled ? truth->records.ptr : nullptr;
+    if (truth->unit_queue.count == 0 && truth->unit_queue.allocate(1) != DS_OK) return DS_E_HIP;
+    args.unit_queue = truth->unit_queue.ptr;  // (one launch at a time per truth table: the handles are not thread-safe)
     args.unit_pairs = ds::pairs_per_unit(d_pair_q ? 0 : k);
     return ds::launch_features(args, truth->device, static_cast<hipStream_t>(stream));
 }
