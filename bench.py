@@ -516,9 +516,14 @@ def main():
                             "kernel skips most of it (MaxScore), so frac_on_survey_8d_bytes exceeds 1 -- a speed-up over "
                             "the reference algorithm's bandwidth floor, not an efficiency.  `traffic` = 2 * FETCH_SIZE + "
                             "WRITE_SIZE per launch from the entry of profiles/pmc_latest.json measured on this build "
-                            "and workload (FETCH_SIZE counts half of coalesced streams on gfx950), else null"}
+                            "and workload (FETCH_SIZE counts half of coalesced streams on gfx950), else null.  `bound` = the roofline "
+                            "this fraction is priced against (SURVEY.md 8d), `limited_by` = what the counters say limits the "
+                            "kernel, `memory_level` = where the index lives (an index of at most 256 MiB is Infinity-Cache "
+                            "resident: 8 TB/s of HBM is then not its memory ceiling)"}
         features_bound_model = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        roofline["frac_on_counter_traffic"] = None
+        roofline["limited_by"] = None
         if os.path.exists(pmc_file):
             with open(pmc_file) as handle:
                 pmc = json.load(handle)
@@ -528,6 +533,17 @@ def main():
                     roofline["traffic"] = entry.get("hbm_bytes_per_launch")
                     roofline["bound_model"] = entry.get("bound_model")
                     features_bound_model = entry.get("features_bound_model")
+                    roofline["counters_source"] = ("profiles/pmc_latest.json: rocprofv3 PMC passes of this build and workload "
+                                                   "(scripts/profile_pmc.sh), NOT measured in this run")
+                    if roofline["traffic"]:
+                        roofline["frac_on_counter_traffic"] = roofline["traffic"] / (mean_topk * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    if isinstance(roofline["bound_model"], dict):
+                        roofline["limited_by"] = roofline["bound_model"].get("binding")
+        # `bound` names the roofline the fraction is priced against (HBM); `limited_by` what the counter model
+        # says holds the kernel (instruction issue: no memory level is near its peak); `memory_level` where the index lives.
+        index_bytes = int(pipeline.index.info()["device_bytes"])
+        roofline["index_bytes"] = index_bytes
+        roofline["memory_level"] = "infinity cache (the index fits its 256 MiB)" if index_bytes <= 256 * 2 ** 20 else "hbm"
         # ds_construct_features_kernel: bound by VALU integer work, not HBM.  Ceiling of the REFERENCE's DP
         # formulation: 256 CUs x 128 lanes per clock (the f32 vector peak of the microarchitecture guide, 157.3 TF = 2 x
         # 256 x 128 x 2.4 GHz) / 5 integer operations per DP cell.  The kernel computes LCS bit-parallel (64 cells per 64-bit

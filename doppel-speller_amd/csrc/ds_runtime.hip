@@ -189,6 +189,10 @@ int ds_device_name(int device, char *name, size_t capacity)
 // The constant per-posting value of match_maker.py:130 is never stored.
 namespace {
 
+#ifndef DS_POSTING_ORDER_DEFAULT
+#define DS_POSTING_ORDER_DEFAULT 0
+#endif
+
 // Everything ds_index_create derives on the host, ready for upload (also digested by ds_index_image_digest for tests).
 struct IndexImage {
     int64_t n_tiles = 0, tile_rows = 0, nnz = 0;
@@ -446,7 +450,10 @@ int build_index_image(const int64_t *rowptr, const int32_t *truth_idx, const flo
     // index, the literal kernels add a column's value to every row of its list, each row once.)
     const uint16_t pad_word = static_cast<uint16_t>(tile_rows / 2);
     std::vector<uint16_t> postings(static_cast<size_t>(quads) * 4), posting_sums(static_cast<size_t>(quads) * 4);
+    const char *order_switch = getenv("DS_POSTING_ORDER");  // 1: bank deal (below); 0: ascending rows
+    const bool bank_deal = order_switch != nullptr ? atoi(order_switch) != 0 : DS_POSTING_ORDER_DEFAULT != 0;
     ds::parallel_dynamic(V, 32, threads, [&](int, int64_t column_begin, int64_t column_end) {
+        std::vector<int32_t> by_bank;
         for (int64_t g = column_begin; g < column_end; ++g) {
             const uint32_t *row = col_ptr.data() + g * stride;
             int64_t p = rowptr[g];
@@ -457,6 +464,51 @@ int build_index_image(const int64_t *rowptr, const int32_t *truth_idx, const flo
                 uint64_t write[2] = {static_cast<uint64_t>(row[b]) * 4u,
                                      (static_cast<uint64_t>(row[b]) + static_cast<uint64_t>(even + 3) / 4u) * 4u};
                 const uint64_t part_end[2] = {write[1], static_cast<uint64_t>(row[b + 1]) * 4u};
+                if (bank_deal) {
+                    // Order of the postings inside a part (round 5): the 32 lanes of a half-wave hold 32 consecutive quads and
+                    // issue their e-th LDS atomic together -- the e-th postings of consecutive quads should lie on different LDS
+                    // banks (word mod 32).  The part's postings are dealt bank after bank, round after round (one posting per
+                    // non-empty bank and round), and laid out slot-major: the i-th dealt posting is slot i / Q of quad i mod Q
+                    // (Q = the part's quads), so that one slot of consecutive quads walks through the banks.
+                    for (int part = 0; part < 2; ++part) {
+                        uint32_t count[33] = {0};
+                        int64_t members = 0;
+                        for (int64_t i = p; i < last; ++i) {
+                            const uint32_t local = static_cast<uint32_t>(truth_idx[i] - tile_first);
+                            if (static_cast<int>(local & 1u) != part) continue;
+                            ++count[((local >> 1) & 31u) + 1];
+                            ++members;
+                        }
+                        if (members == 0) continue;
+                        for (int bank = 0; bank < 32; ++bank) count[bank + 1] += count[bank];  // first place of every bank
+                        by_bank.resize(static_cast<size_t>(members));
+                        uint32_t cursor[32];
+                        for (int bank = 0; bank < 32; ++bank) cursor[bank] = count[bank];
+                        for (int64_t i = p; i < last; ++i) {
+                            const uint32_t local = static_cast<uint32_t>(truth_idx[i] - tile_first);
+                            if (static_cast<int>(local & 1u) == part) by_bank[cursor[(local >> 1) & 31u]++] = truth_idx[i];
+                        }
+                        const uint64_t base = write[part], part_quads = (part_end[part] - base) / 4u;
+                        for (uint64_t i = 0; i < part_quads * 4u; ++i) {  // every place of the part: padding by default
+                            postings[base + i] = static_cast<uint16_t>((part << 15) | pad_word);
+                            posting_sums[base + i] = static_cast<uint16_t>(0xff00);
+                        }
+                        uint64_t dealt = 0;
+                        for (uint32_t round = 0; dealt < static_cast<uint64_t>(members); ++round)
+                            for (int bank = 0; bank < 32; ++bank) {
+                                if (count[bank] + round >= count[bank + 1]) continue;
+                                const int64_t t = by_bank[count[bank] + round];
+                                const uint32_t local = static_cast<uint32_t>(t - tile_first);
+                                const uint64_t at = base + 4u * (dealt % part_quads) + dealt / part_quads;
+                                posting_sums[at] = static_cast<uint16_t>((ds::encode_sums8(sums32[t]) << 8) |
+                                                                          (records[static_cast<size_t>(t) * ds::kRowRecordWords] & 0xffu));
+                                postings[at] = static_cast<uint16_t>(((local & 1u) << 15) | (local >> 1));
+                                ++dealt;
+                            }
+                    }
+                    p = last;
+                    continue;
+                }
                 for (; p < last; ++p) {
                     const int64_t t = truth_idx[p];
                     const uint32_t local = static_cast<uint32_t>(t - tile_first);
