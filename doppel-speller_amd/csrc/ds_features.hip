@@ -905,6 +905,8 @@ static int staged_features(const FeatureInputs &in, int device)
             const int status = stage_chunk(in, staging.slots[static_cast<size_t>(worker)], device, first,
                                            std::min(kStageChunk, in.n - first));
             if (status != DS_OK) {
+                // nothing of this slot may still be in flight when a later call packs its pinned buffers again
+                (void)hipStreamSynchronize(staging.slots[static_cast<size_t>(worker)].stream);
                 failed.store(status);
                 error.raise("%s", ds_last_error());
                 break;

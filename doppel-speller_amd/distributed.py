@@ -73,7 +73,9 @@ def private_directory(base=None):
     if not stat.S_ISDIR(info.st_mode) or info.st_uid != os.getuid():
         raise _lib.DoppelError(f"{path} is not a directory owned by this user")
     if info.st_mode & 0o077:
-        os.chmod(path, 0o700)
+        # somebody else could write here before this call: whatever they planted would stay -- refuse instead of tightening it
+        raise _lib.DoppelError(f"{path} exists with mode {stat.S_IMODE(info.st_mode):o}: group / world access; remove it or "
+                               "pass another base directory")
     return path
 
 

@@ -230,6 +230,7 @@ class MatchMaker:
         self.index = TruthIndex(rowptr, truth_idx, idf32, self.sums_matrix_truth, device)
         self._rows = None
         self._ids = None
+        self._ids_of = None
 
         LOGGER.info(f'[{self.__class__.__name__}] Loaded pre-requisite data!')
 
@@ -290,6 +291,7 @@ class MatchMaker:
         self.index = TruthIndex(arrays["rowptr"], arrays["truth_idx"], arrays["idf32"], arrays["sums32"], device)
         self._rows = None
         self._ids = None
+        self._ids_of = None
         return self
 
     @classmethod
@@ -306,6 +308,7 @@ class MatchMaker:
         self.index = index
         self._rows = None
         self._ids = None
+        self._ids_of = None
         return self
 
     @staticmethod
@@ -361,15 +364,18 @@ class MatchMaker:
         """title_id of every candidate of every row of `data`, [rows, top_n]: `self.truth_data.loc[top_matches, title_id]`
         (:190) for the whole batch in ONE look-up.  The reference pays that `.loc` once per call of get_closest_matches
         (270 us on a 500k-row frame: 27 s for 100k queries, against 16 ms for the kernels); here it is paid once."""
-        if self._ids is None:
+        if self._ids is None or self._ids_of is not self.truth_data:   # (`truth_data` reassigned since: look the ids up again)
             rows = self.get_closest_matches_batch()
             ids = self.truth_data[COLUMN_TITLE_ID]
             index = self.truth_data.index
             positional = (type(index).__name__ == "RangeIndex" and index.start == 0 and index.step == 1)   # common.py:60
             if positional:
                 self._ids = ids.to_numpy()[rows]
-            else:   # any other index: `.loc` keeps its label semantics, still one call
+            elif index.is_unique:   # any other index: `.loc` keeps its label semantics, still one call
                 self._ids = ids.loc[rows.reshape(-1)].to_numpy().reshape(rows.shape)
+            else:   # duplicate labels: `.loc` returns more than one row per label -- per call, as the reference does (:190)
+                return None
+            self._ids_of = self.truth_data
         return self._ids
 
     def _get_top_n_matches(self, top_matches):
@@ -382,7 +388,10 @@ class MatchMaker:
         """
         Given the "row_number" of self.data, gets the closest (self.top_n) titles in self.truth_data
         """
-        ids = self._title_ids()[row_number]
+        table = self._title_ids()
+        if table is None:   # a truth index with duplicate labels: the reference's own per-call look-up, its own outcome
+            return self._get_top_n_matches(self.get_closest_matches_batch([row_number])[0])
+        ids = table[row_number]
         if ids.shape[0] != self.top_n:                                                        # :188-189
             raise Exception('top_matches.shape[0] != self.top_n')
         return ids.tolist()

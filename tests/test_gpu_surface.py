@@ -36,6 +36,25 @@ def test_get_closest_matches_is_a_table_lookup(golden_match_maker):
     for q in (0, 7, 199):
         rows = mm2.get_closest_matches_batch([q])[0]
         assert mm2.get_closest_matches(q) == relabelled.loc[rows, "title_id"].tolist()
+    # `truth_data` reassigned after the first look-up (the reference reads it on every call, :190): the ids follow it
+    first = mm2.get_closest_matches(3)
+    shifted = mm2.truth_data.copy()
+    shifted["title_id"] = shifted["title_id"] + 1_000_000
+    mm2.truth_data = shifted
+    assert mm2.get_closest_matches(3) == [i + 1_000_000 for i in first]
+    # duplicate labels: `.loc` returns every row of a label -- whatever the reference's per-call look-up gives
+    doubled = truth.copy()
+    doubled.index = np.arange(len(truth)) // 2                                   # every label twice
+    data3, _, _ = golden_frames(g)
+    mm3 = ds.MatchMaker(data3, doubled, 10, vocabulary=vocabulary)
+    def outcome(call):   # the list, or the exception the reference's `.loc` raises for a row number that is no label
+        try:
+            return call()
+        except Exception as error:  # noqa: BLE001
+            return type(error).__name__
+    for q in (5, 17, 101):
+        rows = mm3.get_closest_matches_batch([q])[0]
+        assert outcome(lambda: mm3.get_closest_matches(q)) == outcome(lambda: doubled.loc[rows, "title_id"].tolist())
 
 
 def test_nine_argument_construct_features_through_the_staged_path(oracle):

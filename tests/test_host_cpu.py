@@ -236,3 +236,17 @@ def test_reorder_queries_keeps_every_query():
         assert np.array_equal(r.q_cols[r.q_rowptr[i]:r.q_rowptr[i + 1]], w.q_cols[w.q_rowptr[q]:w.q_rowptr[q + 1]])
         assert r.q_maxint[i] == w.q_maxint[q] and np.array_equal(r.q_enc[i], w.q_enc[q]) and r.q_len[i] == w.q_len[q]
         assert r.actual_row[i] == w.actual_row[q]
+
+
+def test_private_directory_refuses_a_directory_others_could_write_to(tmp_path):
+    """an existing ds_<uid> with group / world access is refused, not silently tightened (what somebody else
+    planted there before would stay)."""
+    import os
+    from doppel_speller_amd import _lib
+    from doppel_speller_amd.distributed import private_directory
+    base = str(tmp_path)
+    path = private_directory(base)
+    assert os.stat(path).st_mode & 0o777 == 0o700 and private_directory(base) == path
+    os.chmod(path, 0o770)
+    with pytest.raises(_lib.DoppelError):
+        private_directory(base)
