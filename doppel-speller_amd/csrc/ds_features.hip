@@ -339,6 +339,9 @@ __global__ __launch_bounds__(256) void ds_truth_records_kernel(const uint8_t *en
 
 // kRecords: the truth rows come with their TruthRecord (indexed entry points); without them (the 9-argument entry point: the
 // caller's own arrays, every pair its own copy of both titles) the kernel derives everything itself.
+#ifndef DS_FEAT_POP
+#define DS_FEAT_POP 2           // units a wave takes off the work queue at a time
+#endif
 #ifndef DS_FEAT_MIN_WAVES
 #define DS_FEAT_MIN_WAVES 5   // waves per SIMD the register allocation leaves room for (measured: 4 / 5 / 6 -> C2 1.78 / 1.70 / 1.73 ms, top-100 13.0 / 12.2 / 12.7)
 #endif
@@ -361,11 +364,16 @@ __global__ __launch_bounds__(kFeatKernelWaves * 64, DS_FEAT_MIN_WAVES) void ds_c
     // A wave works through UNITS of `unit_pairs` consecutive pairs, its halves taking alternate pairs: the k candidates of a
     // query are consecutive, so a half stages the query's title (copy, count, squeeze) once for its share of the run -- and
     // both halves work on the SAME query, whose length sets the trip counts of the loops they walk together.
+    int64_t taken_next = 0, taken_end = 0;  // the units this wave has taken off the queue and not worked through yet
     for (int64_t unit = wave_global;; unit += wave_count) {
-        if (a.unit_queue != nullptr) {  // the waves pull their units from a queue: nobody idles while units are left
-            int next = 0;
-            if (lane == 0) next = atomicAdd(a.unit_queue, 1);
-            unit = __builtin_amdgcn_readfirstlane(next);
+        if (a.unit_queue != nullptr) {  // the waves pull their units from a queue: nobody idles while units are left --
+            if (taken_next >= taken_end) {  // DS_FEAT_POP at a time: every pop is an atomic on ONE address (100,000 units: the
+                int next = 0;               // queue itself was a third of C2's launch at one unit per pop, profiles/r05_tuning.txt)
+                if (lane == 0) next = atomicAdd(a.unit_queue, DS_FEAT_POP);
+                taken_next = __builtin_amdgcn_readfirstlane(next);
+                taken_end = taken_next + DS_FEAT_POP;
+            }
+            unit = taken_next++;
         }
         if (unit * unit_pairs >= a.n) break;  // (reached by every wave: the queue head only grows)
         int64_t staged_query = -1;
@@ -985,13 +993,16 @@ static int ensure_truth_records(ds_titles *truth, uint32_t n_truth, uint8_t spac
 }
 
 // consecutive pairs one wave works through (two at a time): the k candidates of a query (k <= 16), a divisor of k between 8 and 16, or 10
+#ifndef DS_FEAT_UNIT
+#define DS_FEAT_UNIT 16
+#endif
 static int32_t pairs_per_unit(int32_t k)
 {
     if (k <= 0) return 8;
-    if (k <= 16) return k;
-    for (int32_t d = 16; d >= 8; --d)
+    if (k <= DS_FEAT_UNIT) return k;
+    for (int32_t d = DS_FEAT_UNIT; d >= (DS_FEAT_UNIT + 1) / 2; --d)
         if (k % d == 0) return d;
-    return 10;
+    return DS_FEAT_UNIT < 10 ? DS_FEAT_UNIT : 10;
 }
 
 }  // namespace ds
