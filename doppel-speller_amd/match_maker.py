@@ -65,8 +65,8 @@ class TruthIndex:
     def info(self):
         raw = (ctypes.c_int64 * 8)()
         _lib.check(_lib.lib().ds_index_info(self.handle, raw), "ds_index_info")
-        keys = ("n_truth", "n_columns", "nnz", "tile_rows", "tiles", "device_bytes", "padded_postings")
-        return dict(zip(keys, list(raw)[:7]))
+        keys = ("n_truth", "n_columns", "nnz", "tile_rows", "tiles", "device_bytes", "padded_postings", "forward_index_bytes")
+        return dict(zip(keys, list(raw)[:8]))
 
     def option(self, name, value):
         """Diagnostics switch of the index (ds_index_option), e.g. option("count_bytes", 1)."""

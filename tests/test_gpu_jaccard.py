@@ -82,6 +82,17 @@ def test_random_against_oracle(oracle, n_truth, k):
     assert index.sync()["error_queries"] == 0
 
 
+def test_more_than_65536_columns_take_the_wide_forward_index(oracle):
+    """The exact stage reads the forward index as uint16 columns while V <= 65536 (every tri-gram vocabulary); an index with
+    more columns (possible through the C ABI) keeps int32 columns and the generic copy of the loop."""
+    rng = np.random.RandomState(4242)
+    problem = _random_problem(rng, 20000, 70000, 96, mean_cols=14)
+    index = _check(oracle, problem, 10)
+    info = index.info()
+    assert info["n_columns"] == 70000 and info["forward_index_bytes"] == 4 * (info["n_truth"] + 1) + 4 * info["nnz"]
+    assert index.sync()["error_queries"] == 0
+
+
 @pytest.mark.parametrize("n_truth,k", [(60000, 200), (90000, 512)])
 def test_large_k_without_sample_threshold(oracle, n_truth, k):
     """k above the sample-threshold limit (128): the first threshold comes from a buffer flood and its recovery."""

@@ -19,6 +19,8 @@ def test_many_tiles_top50_against_oracle(oracle, big_workload):
     pipeline = ds.CandidatePipeline(w, k)
     info = pipeline.index.info()
     assert info["tiles"] == -(-w.n_truth // info["tile_rows"]) and info["tiles"] > 32  # several list-pointer blocks
+    # the forward index in its narrow form (round 5): uint32 row starts, uint16 columns (V <= 65536, nnz < 2^32)
+    assert info["forward_index_bytes"] == 4 * (w.n_truth + 1) + 2 * info["nnz"] and info["forward_index_bytes"] < info["device_bytes"]
     pipeline.step()
     stats = pipeline.sync()
     assert stats["error_queries"] == 0
