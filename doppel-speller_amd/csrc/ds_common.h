@@ -175,6 +175,7 @@ struct ds_titles {
     ds::DeviceBuffer<unsigned char> records;
     uint32_t records_n_truth = 0;
     uint8_t records_space = 0;
-    ds::DeviceBuffer<int32_t> unit_queue;  // head of the features kernel's work queue (indexed entry points)
+    ds::DeviceBuffer<int32_t> unit_queue;  // [64] heads of the features kernel's work queue, one per launch in turn (indexed entry points)
+    size_t unit_queue_next = 0;
     bool records_enabled = true;        // ds_titles_option("truth_records", 0) switches them off (160 B per row of HBM)
 };

@@ -987,6 +987,7 @@ static int ensure_truth_records(ds_titles *truth, uint32_t n_truth, uint8_t spac
                        truth->enc.ptr, truth->stride, truth->len.ptr, truth->counts.ptr, truth->n, n_truth, space_code,
                        reinterpret_cast<TruthRecord *>(truth->records.ptr));
     DS_HIP(hipGetLastError());
+    DS_HIP(hipStreamSynchronize(stream));   // once per (n_truth, space code): complete before a launch on ANY stream reads them
     truth->records_n_truth = n_truth;
     truth->records_space = space_code;
     return DS_OK;
@@ -1103,8 +1104,11 @@ int ds_construct_features_indexed_device(ds_titles *queries, ds_titles *truth, c
     const int ensured = ds::ensure_truth_records(truth, n_truth, space_code, static_cast<hipStream_t>(stream));
     if (ensured != DS_OK) return ensured;
     args.t_records = truth->records_enabled ? truth->records.ptr : nullptr;
-    if (truth->unit_queue.count == 0 && truth->unit_queue.allocate(1) != DS_OK) return DS_E_HIP;
-    args.unit_queue = truth->unit_queue.ptr;  // (one launch at a time per truth table: the handles are not thread-safe)
+    // the launch's work-queue head: one of 64 words of the truth table, taken in turn -- launches that overlap on the device (other
+    // streams) never share a head (the CALLS are still one at a time per table: the handles are not thread-safe)
+    constexpr size_t kQueueHeads = 64;
+    if (truth->unit_queue.count == 0 && truth->unit_queue.allocate(kQueueHeads) != DS_OK) return DS_E_HIP;
+    args.unit_queue = truth->unit_queue.ptr + (truth->unit_queue_next++ % kQueueHeads);
     args.unit_pairs = ds::pairs_per_unit(d_pair_q ? 0 : k);
     return ds::launch_features(args, truth->device, static_cast<hipStream_t>(stream));
 }

@@ -200,3 +200,38 @@ def test_idf_log_matches_libm_for_every_count():
         got = features[:, 36:51].reshape(-1)[:n_truth]
         expected = np.array([math.log(n_truth / c) for c in range(1, n_truth + 1)], dtype=np.float64).astype(np.float32)
         assert np.array_equal(got.view(np.uint32), expected.view(np.uint32))
+
+
+def test_overlapping_launches_on_two_streams_share_one_truth_table(oracle):
+    """Two indexed launches on different streams, enqueued back to back on the same truth table: each pulls its units from a
+    work-queue head of its own (round 5: the heads are taken in turn), every pair is computed exactly once."""
+    import ctypes
+    import doppel_speller_amd as ds
+    from doppel_speller_amd import _lib, synth
+    from doppel_speller_amd.feature_engineering import TitleTable
+    w = synth.make_workload(3000, 400, seed=31)
+    queries, truth = TitleTable(w.q_enc, w.q_len), TitleTable(w.t_enc, w.t_len, w.t_counts)
+    rng = np.random.RandomState(9)
+    k = 10
+    rows = [rng.randint(0, 3000, (400, k)).astype(np.int32) for _ in range(2)]
+    streams, outs, d_rows = [], [], []
+    for r in rows:
+        stream = ctypes.c_void_p()
+        _lib.check(_lib.lib().ds_stream_create(0, ctypes.byref(stream)), "ds_stream_create")
+        streams.append(stream)
+        d_rows.append(_lib.DeviceArray.from_host(r, 0))
+        outs.append(_lib.DeviceArray((r.size, ds.FEATURES_COUNT), np.float32, 0))
+    for repeat in range(3):   # several rounds: the launches of one round overlap, the heads rotate
+        for stream, d_r, out in zip(streams, d_rows, outs):
+            _lib.check(_lib.lib().ds_construct_features_indexed_device(
+                queries.handle, truth.handle, ctypes.c_void_p(0), d_r.ptr, 0, k, ds.SPACE_CODE, w.n_truth, d_r.shape[0] * k,
+                out.ptr, stream), "ds_construct_features_indexed_device")
+    for stream in streams:
+        _lib.check(_lib.lib().ds_stream_sync(stream, 0), "sync")
+    for r, out in zip(rows, outs):
+        pair_q, pair_t = np.repeat(np.arange(400), k), r.reshape(-1)
+        expected = oracle.construct_features(w.q_len[pair_q], w.t_len[pair_t], w.q_enc[pair_q], w.t_enc[pair_t],
+                                             w.t_counts[pair_t], ds.SPACE_CODE, w.n_truth)
+        assert np.array_equal(out.to_host().view(np.uint32), expected.view(np.uint32))
+    for stream in streams:
+        _lib.lib().ds_stream_destroy(stream, 0)
