@@ -17,6 +17,7 @@
 // All strings, masks and the reconstructed title live in LDS; HBM traffic is the title bytes in and 264 B out.
 #include <cmath>
 #include <cstddef>
+#include <map>
 #include <mutex>
 
 #include "ds_common.h"
@@ -798,7 +799,7 @@ struct FeatureSlot {
 };
 
 struct FeatureStaging {
-    std::mutex mutex;   // one call at a time per process (the handles are documented as not thread-safe; this makes it safe)
+    std::mutex mutex;   // one call at a time per device (the handles are documented as not thread-safe; this makes it safe)
     int device = -1;
     std::vector<FeatureSlot> slots;
     int ensure(int wanted_device, int wanted_slots)
@@ -839,9 +840,15 @@ struct FeatureStaging {
     }
 };
 
-static FeatureStaging &feature_staging()
+// One staging set per DEVICE: callers that alternate devices within a process neither serialise on one mutex nor free and
+// re-allocate ~110 MB of pinned buffers at every switch.
+static FeatureStaging &feature_staging(int device)
 {
-    static FeatureStaging *staging = new FeatureStaging();   // never destroyed: no HIP calls from static destructors
+    static std::mutex mutex;
+    static std::map<int, FeatureStaging *> *per_device = new std::map<int, FeatureStaging *>();   // never destroyed: no HIP calls from static destructors
+    std::lock_guard<std::mutex> guard(mutex);
+    FeatureStaging *&staging = (*per_device)[device];
+    if (staging == nullptr) staging = new FeatureStaging();
     return *staging;
 }
 
@@ -891,7 +898,7 @@ static int stage_chunk(const FeatureInputs &in, FeatureSlot &slot, int device, i
 
 static int staged_features(const FeatureInputs &in, int device)
 {
-    FeatureStaging &staging = feature_staging();
+    FeatureStaging &staging = feature_staging(device);
     std::lock_guard<std::mutex> guard(staging.mutex);
     const int64_t chunks = (in.n + kStageChunk - 1) / kStageChunk;
     const int workers = static_cast<int>(std::min<int64_t>(chunks, std::min(host_threads(), kStageMaxSlots)));
