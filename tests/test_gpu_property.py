@@ -2,6 +2,8 @@
 the narrow tile's 12,288-row boundary, heavy ties and twins, rows with one column, queries of 0..128 columns with unseen / zero-IDF /
 every column, k from 1 to the number of rows -- against the oracle, bit for bit, through the C ABI (round 4: forward index in the exact
 stage, split rank counting, two-level collect test, top_n above 512 through the row scan)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,10 @@ hypothesis = pytest.importorskip("hypothesis")
 from hypothesis import HealthCheck, given, settings, strategies as st  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+
+# A soak run (scripts/r05/soak.sh) raises the number of examples and lets hypothesis draw fresh ones:
+# DS_PROPERTY_EXAMPLES=1000 python -m pytest tests/test_gpu_property.py -m gpu
+_SOAK = int(os.environ.get("DS_PROPERTY_EXAMPLES", "0"))
 
 
 def _problem(seed, n_truth, n_columns, shape, n_queries):
@@ -64,7 +70,7 @@ def _problem(seed, n_truth, n_columns, shape, n_queries):
                 q_maxint=np.array(q_maxint, dtype=np.float64))
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@settings(max_examples=_SOAK or 60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=not _SOAK)
 @given(seed=st.integers(0, 2 ** 31 - 1),
        n_truth=st.one_of(st.integers(1, 300), st.integers(12200, 12400), st.integers(24500, 24700), st.integers(300, 30000)),
        n_columns=st.integers(1, 400), shape=st.sampled_from(["random", "twins", "single", "dense"]),
@@ -94,7 +100,7 @@ def test_top_k_equals_the_oracle_on_adversarial_indexes(oracle, seed, n_truth, n
     assert bad.shape[0] == 0, (seed, n_truth, n_columns, shape, k, bad[:4], got[bad[:1]], expected[bad[:1]])
 
 
-@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@settings(max_examples=_SOAK or 40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=not _SOAK)
 @given(seed=st.integers(0, 2 ** 31 - 1), longest=st.sampled_from([1, 3, 16, 33, 64, 65, 127, 128, 200, 255]),
        alphabet=st.sampled_from([2, 4, 38, 64, 200]), space_share=st.sampled_from([0.0, 0.1, 0.5, 1.0]),
        n_truth=st.sampled_from([1, 2, 30000, 50_000_000]))
