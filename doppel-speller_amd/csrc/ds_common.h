@@ -26,7 +26,7 @@ namespace ds {
 #define DS_NARROW_TILE_ROWS 12288
 #endif
 #ifndef DS_NARROW_MAX_TRUTH
-#define DS_NARROW_MAX_TRUTH 10000000  // round 3 (rows in sums32 order): narrow ahead at 2M (22.9 / 24.6 ms) and 5M rows (240 / 249 ms), wide at 50M (385 / 407 ms)
+#define DS_NARROW_MAX_TRUTH 5000000  // round 5 (profiles/r05_tuning.txt section 11), narrow / wide: 3M rows 39.0 / 41.4 ms, 5M 51.1 / 50.8, 7.5M 57.6 / 55.4, 10M 57.2 / 54.1, 20M 80.1 / 72.9
 #endif
 constexpr int kWideTileRows = DS_WIDE_TILE_ROWS, kNarrowTileRows = DS_NARROW_TILE_ROWS;
 constexpr int64_t kNarrowMaxTruth = DS_NARROW_MAX_TRUTH;
