@@ -20,7 +20,7 @@
 #define DS_CANDIDATES DS_WIDE_CANDIDATES
 #define DS_PTR_TILES DS_WIDE_PTR_TILES
 #ifndef DS_WIDE_EPOCH
-#define DS_WIDE_EPOCH 8  // round 3 at the C5 shape (40k queries x 50M rows, top-100): 361.2 (4) / 349.2 (8) / 347.4 ms (16); round 2 at the C3 shape: 91.1 (1) / 88.9 (2) / 86.5 (4) / 85.9 ms (8)
+#define DS_WIDE_EPOCH 16  // round 5 at the C5 shape (20k queries x 50M rows, top-100): 152.6 (4) / 145.8 (8) / 144.1 ms (16); round 3 (40k queries): 361.2 (4) / 349.2 (8) / 347.4 ms (16); round 2 at the C3 shape: 91.1 (1) / 88.9 (2) / 86.5 (4) / 85.9 ms (8)
 #endif
 #define DS_EPOCH_TILES DS_WIDE_EPOCH
 #include "ds_jaccard_impl.inc"

@@ -123,7 +123,8 @@ int ds_jaccard_status(ds_index *index, void *stream, int32_t *status, int64_t Q)
  * `stride` bytes apart (255 in predict.py:199-202), out = float32[n*66] written in place.  Host pointers: the pairs
  * travel in chunks of 16384 through pinned staging buffers (only the titles' own bytes, lengths and word counts are
  * shipped, not the padding), up to 8 host threads with a stream each overlap copy-in / kernel / copy-out; the staging
- * buffers (<= 110 MB pinned) are allocated by the first call and kept.  Calls are serialised by a mutex. */
+ * buffers (<= 110 MB pinned per device) are allocated by a device's first call and kept.  Calls for one device are
+ * serialised by that device's mutex. */
 int ds_construct_features(const uint8_t *q_len, const uint8_t *t_len, const uint8_t *q_enc, const uint8_t *t_enc,
                           const uint32_t *t_word_counts, uint8_t space_code, uint32_t n_truth, int64_t n,
                           int64_t stride, int device, float *out);
