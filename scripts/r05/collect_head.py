@@ -32,7 +32,8 @@ for w in ("c2", "k100", "c3s", "c5s"):
 for name in ("c2", "c2_k100", "c3", "c5shard"):
     source = os.path.join(root, f"gpurun_out/{tag}_{name}_bench.json")
     if os.path.exists(source) and os.path.getsize(source):
-        shutil.copy(source, os.path.join(root, f"profiles/{out}_{name}_bench.json"))
+        line = open(source).read().replace(f"profiles/{tag}_k100_pmc", f"profiles/{out}_c2_k100_pmc").replace(f"profiles/{tag}_", f"profiles/{out}_")
+        open(os.path.join(root, f"profiles/{out}_{name}_bench.json"), "w").write(line)
         d = json.load(open(source))
         r = d["roofline"]
         assert d["build_id"] == bid, (d["build_id"], bid)
